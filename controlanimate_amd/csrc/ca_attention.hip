@@ -1,0 +1,292 @@
+// Flash-style attention for gfx950: O = softmax(Q K^T * scale) V with online softmax.
+//
+// Formulation (everything "transposed" so the softmax state is lane-local):
+//   S^T tile  = mfma(A = K fragment [16 keys x 32 d], B = Q fragment [16 queries x 32 d])
+//               -> lane (g = lane>>4, c = lane&15) holds S^T[key = 4g + r][query = c], r = 0..3.
+//   A query is one lane COLUMN: its running max / sum are per-lane scalars (combined over the
+//   four 16-lane groups with two xor-shuffles), and P^T is already in MFMA B-operand layout.
+//   O^T tile  = mfma(A = V^T fragment [16 dv x 32 keys], B = P^T fragment [32 keys x 16 queries])
+//               -> lane holds O^T[dv = 4g + r][query = c] -> 8-byte stores of 4 consecutive dv.
+// K is staged row-major in LDS; V is staged TRANSPOSED (dv-major) with the key order of every
+// 32-key chunk permuted so that the 8 keys an A-fragment lane needs are one 16-byte read.
+// One kernel serves spatial self-attention, text/IP cross-attention (K/V shared by the frames of
+// a batch element) and temporal attention (strided rows) via the batch/row strides.
+#include "ca_common.h"
+
+namespace {
+
+struct AttnKParams {
+  const u16* q;
+  const u16* k;
+  const u16* v;
+  u16* o;
+  int64_t q_outer, q_inner, q_row;
+  int64_t o_outer, o_inner, o_row;
+  int64_t k_outer, k_inner, k_row;
+  int inner_count, kv_inner_count, kv_div;
+  int batches, heads, head_dim, nq, nk;
+  int qblocks;
+  float scale_log2;
+  float out_scale;
+  int accumulate;
+};
+
+template <int DT, int DK32, int DV16, int QT, int NW, int KB>
+__global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
+  constexpr int NT = NW * 64;
+  constexpr int DKP = DK32 * 32;
+  constexpr int DVP = DV16 * 16;
+  constexpr int KLD = DKP + 8;  // K tile row stride (elements)
+  constexpr int VLD = KB + 8;   // V^T tile row stride (elements)
+  constexpr int KT = KB / 16;
+  constexpr int KC = KB / 32;
+  __shared__ __attribute__((aligned(16))) u16 smem[KB * KLD + DVP * VLD];
+  u16* Ks = smem;
+  u16* Vts = smem + KB * KLD;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  unsigned bid = blockIdx.x;
+  const int qb = bid % p.qblocks;
+  bid /= p.qblocks;
+  const int head = bid % p.heads;
+  const int z = bid / p.heads;
+
+  const int zo = z / p.inner_count, zi = z - zo * p.inner_count;
+  const int zk = z / p.kv_div;
+  const int zko = zk / p.kv_inner_count, zki = zk - zko * p.kv_inner_count;
+  const u16* qp = p.q + zo * p.q_outer + zi * p.q_inner + (int64_t)head * p.head_dim;
+  u16* op = p.o + zo * p.o_outer + zi * p.o_inner + (int64_t)head * p.head_dim;
+  const int64_t kvoff = zko * p.k_outer + zki * p.k_inner + (int64_t)head * p.head_dim;
+  const u16* kp = p.k + kvoff;
+  const u16* vp = p.v + kvoff;
+
+  const int q0 = qb * (NW * QT * 16) + wid * (QT * 16);
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // Q fragments (B operand): Q[q0 + t*16 + l15][kc*32 + g*8 .. +8]
+  u32x4 qf[QT][DK32];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qi = q0 + t * 16 + l15;
+#pragma unroll
+    for (int kc = 0; kc < DK32; ++kc) {
+      const int d = kc * 32 + g * 8;
+      qf[t][kc] = (qi < p.nq && d < p.head_dim) ? ld16(qp + (int64_t)qi * p.q_row + d) : zero4;
+    }
+  }
+
+  f32x4 oacc[QT][DV16];
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    mrun[t] = -INFINITY;
+    lrun[t] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DV16; ++dt) oacc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int kv0 = 0; kv0 < p.nk; kv0 += KB) {
+    __syncthreads();
+    // ---- stage K tile: [KB keys][DKP] row-major, zero padded ------------------------------
+    for (int it = tid; it < KB * (DKP / 8); it += NT) {
+      const int key = it / (DKP / 8), dc = it - key * (DKP / 8);
+      const int kg = kv0 + key;
+      u32x4 val = (kg < p.nk && dc * 8 < p.head_dim) ? ld16(kp + (int64_t)kg * p.k_row + dc * 8) : zero4;
+      st16(Ks + key * KLD + dc * 8, val);
+    }
+    // ---- stage V^T tile: [DVP dv][KB keys (permuted)] ---------------------------------------
+    for (int it = tid; it < (KB / 4) * (DVP / 8); it += NT) {
+      const int quad = it / (DVP / 8), dc = it - quad * (DVP / 8);
+      const int pos = (quad >> 3) * 32 + (quad & 3) * 8 + ((quad >> 2) & 1) * 4;
+      u32x4 r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kg = kv0 + quad * 4 + j;
+        r[j] = (kg < p.nk && dc * 8 < p.head_dim) ? ld16(vp + (int64_t)kg * p.k_row + dc * 8) : zero4;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int w = i >> 1;
+        u32x2 o;
+        if (i & 1) {
+          o[0] = (r[0][w] >> 16) | (r[1][w] & 0xffff0000u);
+          o[1] = (r[2][w] >> 16) | (r[3][w] & 0xffff0000u);
+        } else {
+          o[0] = (r[0][w] & 0xffffu) | (r[1][w] << 16);
+          o[1] = (r[2][w] & 0xffffu) | (r[3][w] << 16);
+        }
+        *reinterpret_cast<u32x2*>(Vts + (dc * 8 + i) * VLD + pos) = o;
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T ----------------------------------------------------------------------
+    f32x4 sacc[QT][KT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) sacc[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int kc = 0; kc < DK32; ++kc) {
+        const u32x4 kf = ld16(Ks + (kt * 16 + l15) * KLD + kc * 32 + g * 8);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) sacc[t][kt] = Elem<DT>::mfma(kf, qf[t][kc], sacc[t][kt]);
+      }
+    }
+
+    // ---- online softmax (per lane = per query column) and P^T fragments ---------------------
+    u32x4 pf[QT][KC];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + kt * 16 + g * 4 + r;
+          float s = key < p.nk ? sacc[t][kt][r] : -INFINITY;
+          sacc[t][kt][r] = s;
+          mloc = fmaxf(mloc, s);
+        }
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      const float mnew = fmaxf(mrun[t], mloc);
+      const float alpha = exp2f((mrun[t] - mnew) * p.scale_log2);
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = exp2f((sacc[t][kt][r] - mnew) * p.scale_log2);
+          sacc[t][kt][r] = pv;
+          psum += pv;
+        }
+      }
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      lrun[t] = lrun[t] * alpha + psum;
+      mrun[t] = mnew;
+#pragma unroll
+      for (int dt = 0; dt < DV16; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[t][dt][r] *= alpha;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        pf[t][c][0] = pack2<DT>(sacc[t][2 * c][0], sacc[t][2 * c][1]);
+        pf[t][c][1] = pack2<DT>(sacc[t][2 * c][2], sacc[t][2 * c][3]);
+        pf[t][c][2] = pack2<DT>(sacc[t][2 * c + 1][0], sacc[t][2 * c + 1][1]);
+        pf[t][c][3] = pack2<DT>(sacc[t][2 * c + 1][2], sacc[t][2 * c + 1][3]);
+      }
+    }
+
+    // ---- O^T += V^T P^T -------------------------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < DV16; ++dt) {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const u32x4 vf = ld16(Vts + (dt * 16 + l15) * VLD + c * 32 + g * 8);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) oacc[t][dt] = Elem<DT>::mfma(vf, pf[t][c], oacc[t][dt]);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds O[q = .. + l15][dv = dt*16 + 4g + r] ------------------------------
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qi = q0 + t * 16 + l15;
+    if (qi >= p.nq) continue;
+    const float inv = p.out_scale / lrun[t];
+    u16* orow = op + (int64_t)qi * p.o_row;
+#pragma unroll
+    for (int dt = 0; dt < DV16; ++dt) {
+      const int dv = dt * 16 + g * 4;
+      if (dv >= p.head_dim) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = oacc[t][dt][r] * inv;
+      if (p.accumulate) {
+        u32x2 old = *reinterpret_cast<const u32x2*>(orow + dv);
+        v[0] += Elem<DT>::to_f((u16)(old[0] & 0xffffu));
+        v[1] += Elem<DT>::to_f((u16)(old[0] >> 16));
+        v[2] += Elem<DT>::to_f((u16)(old[1] & 0xffffu));
+        v[3] += Elem<DT>::to_f((u16)(old[1] >> 16));
+      }
+      u32x2 o;
+      o[0] = pack2<DT>(v[0], v[1]);
+      o[1] = pack2<DT>(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(orow + dv) = o;
+    }
+  }
+}
+
+template <int DT, int DK32, int DV16>
+void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
+  AttnKParams p = p0;
+  if (p.nq <= 16 && p.nk <= 32) {
+    p.qblocks = 1;
+    hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 1, 1, 32>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
+  } else if (p.nq <= 32 && p.nk <= 32) {
+    p.qblocks = 1;
+    hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 1, 32>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
+  } else {
+    p.qblocks = ceil_div_i(p.nq, 128);
+    hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 4, 64>), dim3((unsigned)(p.qblocks * p.batches * p.heads)), dim3(256), 0, st, p);
+  }
+}
+
+template <int DT>
+int launch_attn(const AttnKParams& p, hipStream_t st) {
+  const int d = p.head_dim;
+  if (d <= 32) launch_attn_d<DT, 1, 2>(p, st);
+  else if (d <= 48) launch_attn_d<DT, 2, 3>(p, st);
+  else if (d <= 64) launch_attn_d<DT, 2, 4>(p, st);
+  else if (d <= 80) launch_attn_d<DT, 3, 5>(p, st);
+  else if (d <= 128) launch_attn_d<DT, 4, 8>(p, st);
+  else launch_attn_d<DT, 5, 10>(p, st);
+  return CA_OK;
+}
+
+}  // namespace
+
+extern "C" int ca_attention(const ca_attn_args* a, void* stream) {
+  CA_REQUIRE(a != nullptr, "ca_attention: null args");
+  CA_REQUIRE(a->q && a->k && a->v && a->o, "ca_attention: null operand");
+  CA_REQUIRE(a->head_dim > 0 && a->head_dim % 8 == 0 && a->head_dim <= 160, "ca_attention: head_dim=%d must be a multiple of 8 and <= 160", a->head_dim);
+  CA_REQUIRE(a->batches > 0 && a->heads > 0 && a->nq > 0 && a->nk > 0, "ca_attention: bad sizes");
+  CA_REQUIRE(a->inner_count > 0 && a->kv_inner_count > 0 && a->kv_div > 0, "ca_attention: bad batch decomposition");
+  CA_REQUIRE(a->q_row % 8 == 0 && a->k_row % 8 == 0 && a->o_row % 4 == 0, "ca_attention: row strides misaligned");
+  CA_REQUIRE(a->q_outer % 8 == 0 && a->q_inner % 8 == 0 && a->k_outer % 8 == 0 && a->k_inner % 8 == 0 && a->o_outer % 4 == 0 && a->o_inner % 4 == 0,
+             "ca_attention: batch strides misaligned");
+  CA_REQUIRE(a->dtype == CA_BF16 || a->dtype == CA_F16, "ca_attention: dtype %d", a->dtype);
+  CA_REQUIRE((int64_t)a->batches * a->heads * ceil_div_i(a->nq, 128) < (1ll << 31), "ca_attention: grid too large");
+  AttnKParams p{};
+  p.q = (const u16*)a->q;
+  p.k = (const u16*)a->k;
+  p.v = (const u16*)a->v;
+  p.o = (u16*)a->o;
+  p.q_outer = a->q_outer; p.q_inner = a->q_inner; p.q_row = a->q_row;
+  p.o_outer = a->o_outer; p.o_inner = a->o_inner; p.o_row = a->o_row;
+  p.k_outer = a->k_outer; p.k_inner = a->k_inner; p.k_row = a->k_row;
+  p.inner_count = a->inner_count;
+  p.kv_inner_count = a->kv_inner_count;
+  p.kv_div = a->kv_div;
+  p.batches = a->batches;
+  p.heads = a->heads;
+  p.head_dim = a->head_dim;
+  p.nq = a->nq;
+  p.nk = a->nk;
+  p.scale_log2 = a->scale * 1.4426950408889634f;
+  p.out_scale = a->out_scale;
+  p.accumulate = a->accumulate;
+  if (a->dtype == CA_BF16) launch_attn<CA_BF16>(p, (hipStream_t)stream);
+  else launch_attn<CA_F16>(p, (hipStream_t)stream);
+  CA_CHECK_LAUNCH("ca_attention");
+  return CA_OK;
+}

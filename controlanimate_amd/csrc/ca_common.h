@@ -1,0 +1,101 @@
+// Shared device/host helpers for the gfx950 kernels (wave = 64 lanes, MFMA 16x16x32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/controlanimate_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+
+// ---- host-side error plumbing -------------------------------------------------------
+void ca_set_error(const char* fmt, ...);
+#define CA_FAIL(code, ...)        \
+  do {                            \
+    ca_set_error(__VA_ARGS__);    \
+    return (code);                \
+  } while (0)
+#define CA_REQUIRE(cond, ...)                         \
+  do {                                                \
+    if (!(cond)) CA_FAIL(CA_ERR_INVALID_ARG, __VA_ARGS__); \
+  } while (0)
+#define CA_CHECK_LAUNCH(name)                                                    \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) CA_FAIL(CA_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- element-type traits --------------------------------------------------------------
+template <int DT>
+struct Elem;
+
+template <>
+struct Elem<CA_BF16> {
+  static __device__ __forceinline__ float to_f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
+  static __device__ __forceinline__ u16 from_f(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE) on gfx950
+    return __builtin_bit_cast(u16, b);
+  }
+  static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <>
+struct Elem<CA_F16> {
+  static __device__ __forceinline__ float to_f(u16 h) { return (float)__builtin_bit_cast(_Float16, h); }
+  static __device__ __forceinline__ u16 from_f(float f) {
+    _Float16 b = (_Float16)f;
+    return __builtin_bit_cast(u16, b);
+  }
+  static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <int DT>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  return (unsigned)Elem<DT>::from_f(lo) | ((unsigned)Elem<DT>::from_f(hi) << 16);
+}
+template <int DT>
+__device__ __forceinline__ void unpack8(u32x4 v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = Elem<DT>::to_f((u16)(v[i] & 0xffffu));
+    f[2 * i + 1] = Elem<DT>::to_f((u16)(v[i] >> 16));
+  }
+}
+template <int DT>
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2<DT>(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// Bijective XCD-aware block remap (cdna_hip_programming.md T1): blocks are dispatched
+// round-robin over the 8 XCDs; give each XCD a contiguous range of logical tile ids so that
+// tiles sharing an operand panel hit the same L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned nx = 8;
+  if (nwg < 2 * nx) return bid;
+  unsigned xcd = bid % nx, idx = bid / nx;
+  unsigned q = nwg / nx, r = nwg % nx;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+static inline int ceil_div_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

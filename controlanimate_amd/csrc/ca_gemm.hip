@@ -1,0 +1,361 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution core for gfx950.
+//
+//   C[M,N] = epilogue(A[M,K] * W[N,K]^T),  A dense (linear / 1x1 conv) or gathered on the fly
+//   from an NHWC activation (3x3 conv, pad 1, stride 1/2, optional nearest-x2 upsample and
+//   two-source channel concat).  Both operands are K-contiguous, so MFMA fragments are plain
+//   16-byte reads.
+//
+// Tiling: 256 threads = 4 waves, block tile BM x BN x 64, double-buffered LDS, register-staged
+// global->LDS copies issued one tile ahead (loads in flight during the MFMA phase, written to
+// the other LDS buffer after it: one barrier per K tile).  LDS rows are 128 B (64 elements);
+// the 16-byte chunk index is XOR-swizzled with (row>>1)&7 so that every ds_read_b128 lane group
+// of a fragment read hits 16 distinct 16-B slots (MI355X_MICROARCH.md, LDS table).
+// MFMA is issued with swapped operands (mfma(Wfrag, Afrag)) so each lane ends up holding 4
+// consecutive output columns of one output row -> 8-byte epilogue stores.
+#include "ca_common.h"
+
+namespace {
+
+struct GemmKParams {
+  const u16* a;
+  const u16* a2;
+  const u16* w;
+  void* c;
+  const float* bias;
+  const float* rowbias;
+  const u16* res;
+  int64_t lda, lda2, ldc, ld_res, ld_rowbias;
+  int m, n;
+  int c1, c2;      // channels (K per tap) from source 1 / 2
+  int taps;        // 1 (dense) or 9 (3x3)
+  int kc_tiles;    // ceil((c1+c2)/64)
+  // conv geometry
+  int hin, win, hout, wout, stride, ups;
+  int rows_per_group;
+  float alpha, post;
+  int act, geglu, out_f32;
+};
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+__global__ __launch_bounds__(256) void k_gemm(GemmKParams p) {
+  constexpr int TM = BM / WAVES_M / 16;
+  constexpr int TN = BN / WAVES_N / 16;
+  constexpr int AI = BM / 32;  // A rows per loader thread
+  constexpr int BI = BN / 32;
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * BK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int tiles_n = (p.n + BN - 1) / BN;
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- loader setup -------------------------------------------------------------------
+  const int lr = tid >> 3;  // 0..31
+  const int lc = tid & 7;   // 16-byte chunk within the 64-wide K tile
+  const int kc = p.c1 + p.c2;
+  const int64_t wld = (int64_t)p.taps * kc;
+
+  // per-row state of the A loader
+  int a_img[AI], a_ho[AI], a_wo[AI];
+  bool a_ok[AI];
+  int64_t a_rowoff[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    int m = m0 + lr + 32 * i;
+    a_ok[i] = m < p.m;
+    if (MODE == 1) {
+      int mm = a_ok[i] ? m : 0;
+      int hw = p.hout * p.wout;
+      a_img[i] = mm / hw;
+      int rem = mm - a_img[i] * hw;
+      a_ho[i] = rem / p.wout;
+      a_wo[i] = rem - a_ho[i] * p.wout;
+      a_rowoff[i] = 0;
+    } else {
+      a_img[i] = a_ho[i] = a_wo[i] = 0;
+      a_rowoff[i] = (int64_t)m;
+    }
+  }
+  bool b_ok[BI];
+  int64_t b_rowoff[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    int n = n0 + lr + 32 * i;
+    b_ok[i] = n < p.n;
+    b_rowoff[i] = (int64_t)n * wld;
+  }
+
+  u32x4 ra[AI], rb[BI];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_tile = [&](int t) {
+    int tap = (p.taps == 1) ? 0 : t / p.kc_tiles;
+    int cc = t - tap * p.kc_tiles;
+    int ci = cc * BK + lc * 8;
+    bool cok = ci < kc;
+    // weights
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      rb[i] = (cok && b_ok[i]) ? ld16(p.w + b_rowoff[i] + (int64_t)tap * kc + ci) : zero4;
+    }
+    // activations
+    const bool src2 = ci >= p.c1;
+    const u16* base = src2 ? p.a2 : p.a;
+    const int cs = src2 ? p.c2 : p.c1;
+    const int cio = src2 ? ci - p.c1 : ci;
+    if (MODE == 1) {
+      int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        int hi = a_ho[i] * p.stride + kh - 1;
+        int wi = a_wo[i] * p.stride + kw - 1;
+        bool ok = cok && a_ok[i] && hi >= 0 && wi >= 0 && hi < (p.hin << p.ups) && wi < (p.win << p.ups);
+        int hs = hi >> p.ups, ws = wi >> p.ups;
+        int64_t pix = ((int64_t)a_img[i] * p.hin + hs) * p.win + ws;
+        ra[i] = ok ? ld16(base + pix * cs + cio) : zero4;
+      }
+    } else {
+      const int64_t ld = src2 ? p.lda2 : p.lda;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        ra[i] = (cok && a_ok[i]) ? ld16(base + a_rowoff[i] * ld + cio) : zero4;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    u16* sa = smem + buf * (BM + BN) * BK;
+    u16* sb = sa + BM * BK;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) st16(sa + lds_off(lr + 32 * i, lc), ra[i]);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) st16(sb + lds_off(lr + 32 * i, lc), rb[i]);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.taps * p.kc_tiles;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) load_tile(t + 1);
+    const u16* sa = smem + buf * (BM + BN) * BK;
+    const u16* sb = sa + BM * BK;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = ld16(sa + lds_off(wm * TM * 16 + i * 16 + l15, s * 4 + g));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = ld16(sb + lds_off(wn * TN * 16 + j * 16 + l15, s * 4 + g));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Elem<DT>::mfma(fb[j], fa[i], acc[i][j]);
+    }
+    if (t + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = .. + l15][n = .. + 4g + (0..3)] -----------------------
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * TM * 16 + i * 16 + l15;
+    if (m >= p.m) continue;
+    const float* rbp = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 16 + j * 16 + g * 4;
+      if (n >= p.n) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      if (p.bias) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += b[r];
+      }
+      if (rbp) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(rbp + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += b[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+      if (p.res) {
+        u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + (int64_t)m * p.ld_res + n);
+        v[0] += Elem<DT>::to_f((u16)(rr[0] & 0xffffu));
+        v[1] += Elem<DT>::to_f((u16)(rr[0] >> 16));
+        v[2] += Elem<DT>::to_f((u16)(rr[1] & 0xffffu));
+        v[3] += Elem<DT>::to_f((u16)(rr[1] >> 16));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= p.post;
+      if (p.act == CA_ACT_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+      }
+      if (p.geglu) {
+        float o0 = v[0] * gelu_erf_f(v[1]);
+        float o1 = v[2] * gelu_erf_f(v[3]);
+        const int64_t off = (int64_t)m * p.ldc + (n >> 1);
+        if (p.out_f32) {
+          float* cp = reinterpret_cast<float*>(p.c) + off;
+          cp[0] = o0;
+          cp[1] = o1;
+        } else {
+          *reinterpret_cast<unsigned*>(reinterpret_cast<u16*>(p.c) + off) = pack2<DT>(o0, o1);
+        }
+      } else {
+        const int64_t off = (int64_t)m * p.ldc + n;
+        if (p.out_f32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + off) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+          u32x2 o;
+          o[0] = pack2<DT>(v[0], v[1]);
+          o[1] = pack2<DT>(v[2], v[3]);
+          *reinterpret_cast<u32x2*>(reinterpret_cast<u16*>(p.c) + off) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int DT, int MODE>
+int launch_gemm(const GemmKParams& p, hipStream_t st) {
+  // N multiple of 128 -> 128x128 tile; otherwise 128x64 (exact for 320 / 960 wide outputs).
+  if (p.n % 128 == 0) {
+    int tiles = ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128);
+    hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
+  } else {
+    int tiles = ceil_div_i(p.m, 128) * ceil_div_i(p.n, 64);
+    hipLaunchKernelGGL((k_gemm<DT, 128, 64, 4, 1, MODE>), dim3(tiles), dim3(256), 0, st, p);
+  }
+  return CA_OK;
+}
+
+int check_epilogue(const char* who, int n, int geglu, int out_f32, int64_t ldc, int64_t ld_res, const void* res) {
+  CA_REQUIRE(n > 0 && n % 4 == 0, "%s: N=%d must be a positive multiple of 4", who, n);
+  CA_REQUIRE(!geglu || n % 8 == 0, "%s: geglu needs N %% 8 == 0", who);
+  CA_REQUIRE(ldc % (geglu ? 2 : 4) == 0, "%s: ldc=%lld misaligned", who, (long long)ldc);
+  CA_REQUIRE(!res || ld_res % 4 == 0, "%s: ld_res=%lld misaligned", who, (long long)ld_res);
+  (void)out_f32;
+  return CA_OK;
+}
+
+}  // namespace
+
+extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
+  CA_REQUIRE(a != nullptr, "ca_gemm: null args");
+  CA_REQUIRE(a->a && a->w && a->c, "ca_gemm: null operand");
+  CA_REQUIRE(a->m > 0 && a->k1 > 0 && a->k2 >= 0, "ca_gemm: bad sizes m=%d k1=%d k2=%d", a->m, a->k1, a->k2);
+  CA_REQUIRE(a->k1 % 8 == 0 && a->k2 % 8 == 0, "ca_gemm: k1=%d k2=%d must be multiples of 8", a->k1, a->k2);
+  CA_REQUIRE(a->lda % 8 == 0 && (a->k2 == 0 || (a->a2 && a->lda2 % 8 == 0)), "ca_gemm: lda/lda2 misaligned or a2 missing");
+  CA_REQUIRE(a->dtype == CA_BF16 || a->dtype == CA_F16, "ca_gemm: dtype %d", a->dtype);
+  CA_REQUIRE(!a->rowbias || a->rows_per_group > 0, "ca_gemm: rows_per_group");
+  CA_REQUIRE(!a->rowbias || a->ld_rowbias % 4 == 0, "ca_gemm: ld_rowbias misaligned");
+  int rc = check_epilogue("ca_gemm", a->n, a->geglu, a->out_f32, a->ldc, a->ld_res, a->residual);
+  if (rc) return rc;
+  GemmKParams p{};
+  p.a = (const u16*)a->a;
+  p.a2 = (const u16*)a->a2;
+  p.w = (const u16*)a->w;
+  p.c = a->c;
+  p.bias = a->bias;
+  p.rowbias = a->rowbias;
+  p.res = (const u16*)a->residual;
+  p.lda = a->lda;
+  p.lda2 = a->lda2;
+  p.ldc = a->ldc;
+  p.ld_res = a->ld_res;
+  p.ld_rowbias = a->ld_rowbias;
+  p.m = a->m;
+  p.n = a->n;
+  p.c1 = a->k1;
+  p.c2 = a->k2;
+  p.taps = 1;
+  p.kc_tiles = ceil_div_i(a->k1 + a->k2, BK);
+  p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
+  p.alpha = a->alpha;
+  p.post = a->post_scale;
+  p.act = a->act;
+  p.geglu = a->geglu;
+  p.out_f32 = a->out_f32;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 0>(p, st);
+  else launch_gemm<CA_F16, 0>(p, st);
+  CA_CHECK_LAUNCH("ca_gemm");
+  return CA_OK;
+}
+
+extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
+  CA_REQUIRE(a != nullptr, "ca_conv3x3: null args");
+  CA_REQUIRE(a->x && a->w && a->y, "ca_conv3x3: null operand");
+  CA_REQUIRE(a->images > 0 && a->hin > 0 && a->win > 0, "ca_conv3x3: bad geometry");
+  CA_REQUIRE(a->cin1 > 0 && a->cin1 % 8 == 0 && a->cin2 >= 0 && a->cin2 % 8 == 0,
+             "ca_conv3x3: cin1=%d cin2=%d must be multiples of 8", a->cin1, a->cin2);
+  CA_REQUIRE(a->cin2 == 0 || a->x2, "ca_conv3x3: x2 missing");
+  CA_REQUIRE(a->stride == 1 || a->stride == 2, "ca_conv3x3: stride %d", a->stride);
+  CA_REQUIRE(a->upsample == 0 || a->upsample == 1, "ca_conv3x3: upsample %d", a->upsample);
+  CA_REQUIRE(a->dtype == CA_BF16 || a->dtype == CA_F16, "ca_conv3x3: dtype %d", a->dtype);
+  CA_REQUIRE(!a->rowbias || a->rows_per_group > 0, "ca_conv3x3: rows_per_group");
+  int rc = check_epilogue("ca_conv3x3", a->cout, 0, a->out_f32, a->cout, a->ld_res, a->residual);
+  if (rc) return rc;
+  const int hl = a->hin << a->upsample, wl = a->win << a->upsample;
+  const int hout = (hl + 2 - 3) / a->stride + 1;
+  const int wout = (wl + 2 - 3) / a->stride + 1;
+  const int64_t m64 = (int64_t)a->images * hout * wout;
+  CA_REQUIRE(m64 < (1ll << 31), "ca_conv3x3: too many output pixels");
+  GemmKParams p{};
+  p.a = (const u16*)a->x;
+  p.a2 = (const u16*)a->x2;
+  p.w = (const u16*)a->w;
+  p.c = a->y;
+  p.bias = a->bias;
+  p.rowbias = a->rowbias;
+  p.res = (const u16*)a->residual;
+  p.ldc = a->cout;
+  p.ld_res = a->ld_res;
+  p.ld_rowbias = a->ld_rowbias;
+  p.m = (int)m64;
+  p.n = a->cout;
+  p.c1 = a->cin1;
+  p.c2 = a->cin2;
+  p.taps = 9;
+  p.kc_tiles = ceil_div_i(a->cin1 + a->cin2, BK);
+  p.hin = a->hin;
+  p.win = a->win;
+  p.hout = hout;
+  p.wout = wout;
+  p.stride = a->stride;
+  p.ups = a->upsample;
+  p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
+  p.alpha = a->alpha;
+  p.post = a->post_scale;
+  p.act = a->act;
+  p.geglu = 0;
+  p.out_f32 = a->out_f32;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 1>(p, st);
+  else launch_gemm<CA_F16, 1>(p, st);
+  CA_CHECK_LAUNCH("ca_conv3x3");
+  return CA_OK;
+}

@@ -1,0 +1,322 @@
+// GroupNorm(+SiLU) and LayerNorm(+positional table) for channels-last activations (gfx950).
+// Both are HBM-bound: 16-byte vector accesses, fp32 statistics, wavefront (64-lane) shuffles.
+#include "ca_common.h"
+
+namespace {
+
+constexpr int GN_MAX_SLOTS = 5;  // 64 lanes * 8 channels * 5 = 2560 channels
+constexpr int GN_MAX_C = 64 * 8 * GN_MAX_SLOTS;
+
+inline int gn_chunks_host(int64_t rows_per_stat) {
+  int64_t n = (rows_per_stat + 63) / 64;
+  if (n < 1) n = 1;
+  if (n > 256) n = 256;
+  return (int)n;
+}
+
+struct GnParams {
+  const u16* x;
+  const u16* x2;
+  u16* y;
+  const float* gamma;
+  const float* beta;
+  float* partials;
+  int c1, c2, groups;
+  int64_t rows_per_stat;  // frames_per_stat * hw
+  int nchunks;
+  int64_t rows_per_chunk;
+  float eps;
+  int act;
+};
+
+// grid: (nchunks, n_stat_groups). block 256 = 64 channel-chunk lanes x 4 row lanes.
+template <int DT>
+__global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
+  __shared__ float ch_s[GN_MAX_C];
+  __shared__ float ch_ss[GN_MAX_C];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int C = p.c1 + p.c2, C8 = C >> 3;
+  const int chunk = blockIdx.x, sg = blockIdx.y;
+  const int64_t r0 = (int64_t)chunk * p.rows_per_chunk;
+  int64_t r1 = r0 + p.rows_per_chunk;
+  if (r1 > p.rows_per_stat) r1 = p.rows_per_stat;
+  const int64_t base_row = (int64_t)sg * p.rows_per_stat;
+
+  float s[GN_MAX_SLOTS][8], ss[GN_MAX_SLOTS][8];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[k][j] = ss[k][j] = 0.f;
+
+  for (int64_t r = r0 + ty; r < r1; r += 4) {
+    const int64_t row = base_row + r;
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      const int c8 = tx + 64 * k;
+      if (c8 < C8) {
+        const int ch = c8 << 3;
+        const u16* src = ch < p.c1 ? p.x + row * p.c1 + ch : p.x2 + row * p.c2 + (ch - p.c1);
+        float f[8];
+        unpack8<DT>(ld16(src), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s[k][j] += f[j];
+          ss[k][j] += f[j] * f[j];
+        }
+      }
+    }
+  }
+  // deterministic cross-wave reduction through LDS, one wave at a time
+  for (int w = 0; w < 4; ++w) {
+    if (ty == w) {
+#pragma unroll
+      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int c8 = tx + 64 * k;
+        if (c8 < C8) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ch = (c8 << 3) + j;
+            if (w == 0) {
+              ch_s[ch] = s[k][j];
+              ch_ss[ch] = ss[k][j];
+            } else {
+              ch_s[ch] += s[k][j];
+              ch_ss[ch] += ss[k][j];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int cpg = C / p.groups;
+  if (threadIdx.x < p.groups) {
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < cpg; ++j) {
+      a += ch_s[threadIdx.x * cpg + j];
+      b += ch_ss[threadIdx.x * cpg + j];
+    }
+    float* out = p.partials + (((int64_t)sg * p.nchunks + chunk) * p.groups + threadIdx.x) * 2;
+    out[0] = a;
+    out[1] = b;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
+  __shared__ float sc[GN_MAX_C];
+  __shared__ float sh[GN_MAX_C];
+  __shared__ float gm[64], gr[64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int C = p.c1 + p.c2, C8 = C >> 3;
+  const int chunk = blockIdx.x, sg = blockIdx.y;
+  const int cpg = C / p.groups;
+  if (threadIdx.x < p.groups) {
+    double a = 0.0, b = 0.0;
+    const float* part = p.partials + ((int64_t)sg * p.nchunks * p.groups + threadIdx.x) * 2;
+    for (int k = 0; k < p.nchunks; ++k) {
+      a += (double)part[(int64_t)k * p.groups * 2];
+      b += (double)part[(int64_t)k * p.groups * 2 + 1];
+    }
+    const double cnt = (double)p.rows_per_stat * (double)cpg;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gm[threadIdx.x] = (float)mean;
+    gr[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int gi = c / cpg;
+    const float scale = gr[gi] * p.gamma[c];
+    sc[c] = scale;
+    sh[c] = p.beta[c] - gm[gi] * scale;
+  }
+  __syncthreads();
+
+  const int64_t r0 = (int64_t)chunk * p.rows_per_chunk;
+  int64_t r1 = r0 + p.rows_per_chunk;
+  if (r1 > p.rows_per_stat) r1 = p.rows_per_stat;
+  const int64_t base_row = (int64_t)sg * p.rows_per_stat;
+  for (int64_t r = r0 + ty; r < r1; r += 4) {
+    const int64_t row = base_row + r;
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      const int c8 = tx + 64 * k;
+      if (c8 < C8) {
+        const int ch = c8 << 3;
+        const u16* src = ch < p.c1 ? p.x + row * p.c1 + ch : p.x2 + row * p.c2 + (ch - p.c1);
+        float f[8];
+        unpack8<DT>(ld16(src), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = f[j] * sc[ch + j] + sh[ch + j];
+          f[j] = p.act == CA_ACT_SILU ? silu_f(v) : v;
+        }
+        st16(p.y + row * C + ch, pack8<DT>(f));
+      }
+    }
+  }
+}
+
+int gn_fill(const ca_groupnorm_args* a, GnParams& p, const char* who) {
+  CA_REQUIRE(a != nullptr, "%s: null args", who);
+  CA_REQUIRE(a->x && a->partials, "%s: null operand", who);
+  CA_REQUIRE(a->c1 > 0 && a->c1 % 8 == 0 && a->c2 >= 0 && a->c2 % 8 == 0, "%s: c1=%d c2=%d must be multiples of 8", who, a->c1, a->c2);
+  CA_REQUIRE(a->c2 == 0 || a->x2, "%s: x2 missing", who);
+  const int C = a->c1 + a->c2;
+  CA_REQUIRE(C <= GN_MAX_C, "%s: C=%d exceeds %d", who, C, GN_MAX_C);
+  CA_REQUIRE(a->groups > 0 && a->groups <= 64 && C % a->groups == 0, "%s: groups=%d does not divide C=%d", who, a->groups, C);
+  CA_REQUIRE(a->frames_per_stat > 0 && a->images % a->frames_per_stat == 0, "%s: frames_per_stat=%d does not divide images=%d", who, a->frames_per_stat, a->images);
+  CA_REQUIRE(a->hw > 0, "%s: hw", who);
+  CA_REQUIRE(a->dtype == CA_BF16 || a->dtype == CA_F16, "%s: dtype %d", who, a->dtype);
+  p.x = (const u16*)a->x;
+  p.x2 = (const u16*)a->x2;
+  p.y = (u16*)a->y;
+  p.gamma = a->gamma;
+  p.beta = a->beta;
+  p.partials = a->partials;
+  p.c1 = a->c1;
+  p.c2 = a->c2;
+  p.groups = a->groups;
+  p.rows_per_stat = (int64_t)a->frames_per_stat * a->hw;
+  p.nchunks = gn_chunks_host(p.rows_per_stat);
+  p.rows_per_chunk = (p.rows_per_stat + p.nchunks - 1) / p.nchunks;
+  p.eps = a->eps;
+  p.act = a->act;
+  return CA_OK;
+}
+
+// ---- LayerNorm ----------------------------------------------------------------------------
+constexpr int LN_MAX_SLOTS = 4;  // C <= 2048
+
+struct LnParams {
+  const u16* x;
+  u16* y;
+  const float* gamma;
+  const float* beta;
+  const float* pos;
+  int64_t rows;
+  int c;
+  int rows_per_frame, frames;
+  float eps;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int C8 = p.c >> 3;
+  const float inv_c = 1.0f / (float)p.c;
+  for (int64_t row = wave; row < p.rows; row += nwaves) {
+    float f[LN_MAX_SLOTS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAX_SLOTS; ++k) {
+      const int c8 = lane + 64 * k;
+      if (c8 < C8) {
+        unpack8<DT>(ld16(p.x + row * p.c + (c8 << 3)), f[k]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += f[k][j];
+      }
+    }
+    const float mean = wave_sum(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAX_SLOTS; ++k) {
+      const int c8 = lane + 64 * k;
+      if (c8 < C8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = f[k][j] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_c + p.eps);
+    const float* pos = nullptr;
+    if (p.pos) {
+      const int64_t fr = (row / p.rows_per_frame) % p.frames;
+      pos = p.pos + fr * p.c;
+    }
+#pragma unroll
+    for (int k = 0; k < LN_MAX_SLOTS; ++k) {
+      const int c8 = lane + 64 * k;
+      if (c8 < C8) {
+        const int ch = c8 << 3;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = (f[k][j] - mean) * rstd * p.gamma[ch + j] + p.beta[ch + j];
+          if (pos) v += pos[ch + j];
+          o[j] = v;
+        }
+        st16(p.y + row * p.c + ch, pack8<DT>(o));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t ca_groupnorm_partials_floats(int32_t images, int32_t hw, int32_t frames_per_stat, int32_t groups) {
+  if (images <= 0 || hw <= 0 || frames_per_stat <= 0 || groups <= 0) return 0;
+  const int64_t nstat = images / frames_per_stat;
+  return nstat * gn_chunks_host((int64_t)frames_per_stat * hw) * groups * 2;
+}
+
+extern "C" int ca_groupnorm_stats(const ca_groupnorm_args* a, void* stream) {
+  GnParams p{};
+  int rc = gn_fill(a, p, "ca_groupnorm_stats");
+  if (rc) return rc;
+  dim3 grid(p.nchunks, a->images / a->frames_per_stat);
+  if (a->dtype == CA_BF16) hipLaunchKernelGGL(k_gn_stats<CA_BF16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(k_gn_stats<CA_F16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  CA_CHECK_LAUNCH("ca_groupnorm_stats");
+  return CA_OK;
+}
+
+extern "C" int ca_groupnorm_apply(const ca_groupnorm_args* a, void* stream) {
+  GnParams p{};
+  int rc = gn_fill(a, p, "ca_groupnorm_apply");
+  if (rc) return rc;
+  CA_REQUIRE(a->y && a->gamma && a->beta, "ca_groupnorm_apply: null operand");
+  dim3 grid(p.nchunks, a->images / a->frames_per_stat);
+  if (a->dtype == CA_BF16) hipLaunchKernelGGL(k_gn_apply<CA_BF16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(k_gn_apply<CA_F16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  CA_CHECK_LAUNCH("ca_groupnorm_apply");
+  return CA_OK;
+}
+
+extern "C" int ca_layernorm(const ca_layernorm_args* a, void* stream) {
+  CA_REQUIRE(a != nullptr, "ca_layernorm: null args");
+  CA_REQUIRE(a->x && a->y && a->gamma && a->beta, "ca_layernorm: null operand");
+  CA_REQUIRE(a->rows > 0, "ca_layernorm: rows");
+  CA_REQUIRE(a->c > 0 && a->c % 8 == 0 && a->c <= 64 * 8 * LN_MAX_SLOTS, "ca_layernorm: C=%d must be a multiple of 8 and <= %d", a->c, 64 * 8 * LN_MAX_SLOTS);
+  CA_REQUIRE(!a->pos || (a->rows_per_frame > 0 && a->frames > 0), "ca_layernorm: pos needs rows_per_frame/frames");
+  CA_REQUIRE(a->dtype == CA_BF16 || a->dtype == CA_F16, "ca_layernorm: dtype %d", a->dtype);
+  LnParams p{};
+  p.x = (const u16*)a->x;
+  p.y = (u16*)a->y;
+  p.gamma = a->gamma;
+  p.beta = a->beta;
+  p.pos = a->pos;
+  p.rows = a->rows;
+  p.c = a->c;
+  p.rows_per_frame = a->rows_per_frame > 0 ? a->rows_per_frame : 1;
+  p.frames = a->frames > 0 ? a->frames : 1;
+  p.eps = a->eps;
+  int64_t blocks = (a->rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  if (a->dtype == CA_BF16) hipLaunchKernelGGL(k_layernorm<CA_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(k_layernorm<CA_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  CA_CHECK_LAUNCH("ca_layernorm");
+  return CA_OK;
+}

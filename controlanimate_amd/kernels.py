@@ -1,0 +1,301 @@
+"""Thin torch-tensor front end of the C ABI (device pointers + current HIP stream).
+
+torch is used only for device memory and streams; every arithmetic op below is a call into
+`libcontrolanimate_hip.so`.  All activations are channels-last ("NHWC"): `[images, H, W, C]`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _capi
+from ._capi import (AttnArgs, ConvArgs, GemmArgs, GroupNormArgs, LayerNormArgs, CA_ACT_NONE,
+                    CA_ACT_SILU, CA_BF16, CA_F16, check, lib)
+
+ACT_NONE, ACT_SILU = CA_ACT_NONE, CA_ACT_SILU
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.bfloat16:
+        return CA_BF16
+    if dtype == torch.float16:
+        return CA_F16
+    raise TypeError(f"activations must be bf16 or fp16, got {dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _capi.CAHipError("HIP kernels need device tensors (no CPU fallback)")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
+         bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
+         rows_per_group: int = 0, residual: Optional[torch.Tensor] = None, alpha: float = 1.0,
+         post_scale: float = 1.0, act: int = ACT_NONE, geglu: bool = False, out_f32: bool = False,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = epilogue(cat(a, a2)[M, K] @ w[N, K]^T); see ca_gemm in the header."""
+    _req_cuda(a, w, a2, bias, rowbias, residual, out)
+    assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous()
+    m, k1 = a.shape
+    k2 = 0
+    if a2 is not None:
+        assert a2.dim() == 2 and a2.stride(1) == 1 and a2.shape[0] == m and a2.dtype == a.dtype
+        k2 = a2.shape[1]
+    n = w.shape[0]
+    assert w.shape[1] == k1 + k2 and w.dtype == a.dtype
+    ncols = n // 2 if geglu else n
+    if out is None:
+        out = torch.empty((m, ncols), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    assert out.shape == (m, ncols) and out.stride(1) == 1
+    if residual is not None:
+        assert residual.shape == (m, n) and residual.stride(1) == 1 and residual.dtype == a.dtype
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == n
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.dim() == 2 and rowbias.shape[1] == n and rows_per_group > 0
+    args = GemmArgs(a=_p(a), a2=_p(a2), w=_p(w), c=_p(out), bias=_p(bias), rowbias=_p(rowbias),
+                    residual=_p(residual), lda=a.stride(0), lda2=a2.stride(0) if a2 is not None else 0,
+                    ldc=out.stride(0), ld_res=residual.stride(0) if residual is not None else 0,
+                    ld_rowbias=rowbias.stride(0) if rowbias is not None else 0,
+                    m=m, n=n, k1=k1, k2=k2, rows_per_group=rows_per_group, alpha=alpha,
+                    post_scale=post_scale, act=act, geglu=int(geglu), out_f32=int(out_f32),
+                    dtype=dt_code(a.dtype))
+    check(lib().ca_gemm(C.byref(args), _stream()), "ca_gemm")
+    return out
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = None,
+            bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
+            rows_per_group: int = 0, residual: Optional[torch.Tensor] = None, stride: int = 1,
+            upsample: bool = False, alpha: float = 1.0, post_scale: float = 1.0, act: int = ACT_NONE,
+            out_f32: bool = False) -> torch.Tensor:
+    """x: [images, H, W, Cin1] (+x2 [.., Cin2]); w: [Cout, 3, 3, Cin1+Cin2]; returns NHWC."""
+    _req_cuda(x, w, x2, bias, rowbias, residual)
+    assert x.dim() == 4 and x.is_contiguous() and w.dim() == 4 and w.is_contiguous()
+    images, hin, win, cin1 = x.shape
+    cin2 = 0
+    if x2 is not None:
+        assert x2.is_contiguous() and x2.shape[:3] == x.shape[:3] and x2.dtype == x.dtype
+        cin2 = x2.shape[3]
+    cout = w.shape[0]
+    assert tuple(w.shape[1:]) == (3, 3, cin1 + cin2) and w.dtype == x.dtype
+    hl, wl = (hin * 2, win * 2) if upsample else (hin, win)
+    hout, wout = (hl - 1) // stride + 1, (wl - 1) // stride + 1
+    y = torch.empty((images, hout, wout, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    ld_res = 0
+    if residual is not None:
+        assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == images * hout * wout * cout
+        ld_res = cout
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.dim() == 2 and rowbias.shape[1] == cout and rows_per_group > 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == cout
+    args = ConvArgs(x=_p(x), x2=_p(x2), w=_p(w), y=_p(y), bias=_p(bias), rowbias=_p(rowbias),
+                    residual=_p(residual), ld_res=ld_res,
+                    ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, images=images, hin=hin,
+                    win=win, cin1=cin1, cin2=cin2, cout=cout, stride=stride, upsample=int(upsample),
+                    rows_per_group=rows_per_group, alpha=alpha, post_scale=post_scale, act=act,
+                    out_f32=int(out_f32), dtype=dt_code(x.dtype))
+    check(lib().ca_conv3x3(C.byref(args), _stream()), "ca_conv3x3")
+    return y
+
+
+def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, x2: Optional[torch.Tensor] = None,
+               groups: int = 32, frames_per_stat: int = 1, eps: float = 1e-5, act: int = ACT_NONE) -> torch.Tensor:
+    """GroupNorm (+SiLU) over NHWC x (optionally channel-concatenated with x2)."""
+    _req_cuda(x, gamma, beta, x2)
+    assert x.dim() == 4 and x.is_contiguous()
+    images, h, w_, c1 = x.shape
+    c2 = 0
+    if x2 is not None:
+        assert x2.is_contiguous() and x2.shape[:3] == x.shape[:3] and x2.dtype == x.dtype
+        c2 = x2.shape[3]
+    c = c1 + c2
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == c and beta.numel() == c
+    y = torch.empty((images, h, w_, c), device=x.device, dtype=x.dtype)
+    nfl = lib().ca_groupnorm_partials_floats(images, h * w_, frames_per_stat, groups)
+    partials = torch.empty((max(int(nfl), 1),), device=x.device, dtype=torch.float32)
+    args = GroupNormArgs(x=_p(x), x2=_p(x2), y=_p(y), gamma=_p(gamma), beta=_p(beta), partials=_p(partials),
+                         images=images, hw=h * w_, c1=c1, c2=c2, groups=groups,
+                         frames_per_stat=frames_per_stat, eps=eps, act=act, dtype=dt_code(x.dtype))
+    st = _stream()
+    check(lib().ca_groupnorm_stats(C.byref(args), st), "ca_groupnorm_stats")
+    check(lib().ca_groupnorm_apply(C.byref(args), st), "ca_groupnorm_apply")
+    return y
+
+
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, pos: Optional[torch.Tensor] = None,
+               rows_per_frame: int = 1, frames: int = 1, eps: float = 1e-5) -> torch.Tensor:
+    _req_cuda(x, gamma, beta, pos)
+    assert x.dim() == 2 and x.is_contiguous()
+    rows, c = x.shape
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    if pos is not None:
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape == (frames, c)
+    y = torch.empty_like(x)
+    args = LayerNormArgs(x=_p(x), y=_p(y), gamma=_p(gamma), beta=_p(beta), pos=_p(pos), rows=rows, c=c,
+                         rows_per_frame=rows_per_frame, frames=frames, eps=eps, dtype=dt_code(x.dtype))
+    check(lib().ca_layernorm(C.byref(args), _stream()), "ca_layernorm")
+    return y
+
+
+def attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, *, q_off: int, k_off: int,
+                  v_off: int, o_off: int, q_strides, o_strides, k_strides, inner_count: int, kv_inner_count: int,
+                  kv_div: int, batches: int, heads: int, head_dim: int, nq: int, nk: int, scale: float,
+                  out_scale: float = 1.0, accumulate: bool = False) -> None:
+    """Direct mapping of ca_attention. *_off are element offsets into the given storage tensors;
+    *_strides = (outer, inner, row) in elements."""
+    _req_cuda(q, k, v, o)
+    es = q.element_size()
+    args = AttnArgs(q=q.data_ptr() + q_off * es, k=k.data_ptr() + k_off * es, v=v.data_ptr() + v_off * es,
+                    o=o.data_ptr() + o_off * es,
+                    q_outer=q_strides[0], q_inner=q_strides[1], q_row=q_strides[2],
+                    o_outer=o_strides[0], o_inner=o_strides[1], o_row=o_strides[2],
+                    k_outer=k_strides[0], k_inner=k_strides[1], k_row=k_strides[2],
+                    inner_count=inner_count, kv_inner_count=kv_inner_count, kv_div=kv_div, batches=batches,
+                    heads=heads, head_dim=head_dim, nq=nq, nk=nk, scale=scale, out_scale=out_scale,
+                    accumulate=int(accumulate), dtype=dt_code(q.dtype))
+    check(lib().ca_attention(C.byref(args), _stream()), "ca_attention")
+
+
+def attention_spatial(qkv: torch.Tensor, images: int, tokens: int, heads: int) -> torch.Tensor:
+    """Self-attention per image. qkv: [images*tokens, 3C] (q | k | v); returns [images*tokens, C]."""
+    c = qkv.shape[1] // 3
+    d = c // heads
+    o = torch.empty((images * tokens, c), device=qkv.device, dtype=qkv.dtype)
+    ld = qkv.stride(0)
+    attention_raw(qkv, qkv, qkv, o, q_off=0, k_off=c, v_off=2 * c, o_off=0,
+                  q_strides=(tokens * ld, 0, ld), o_strides=(tokens * c, 0, c), k_strides=(tokens * ld, 0, ld),
+                  inner_count=1, kv_inner_count=1, kv_div=1, batches=images, heads=heads, head_dim=d,
+                  nq=tokens, nk=tokens, scale=d ** -0.5)
+    return o
+
+
+def attention_cross(q: torch.Tensor, kv: torch.Tensor, images: int, tokens: int, heads: int, kv_tokens: int,
+                    kv_rows_per_batch: int, frames_per_kv: int, *, out: Optional[torch.Tensor] = None,
+                    out_scale: float = 1.0, accumulate: bool = False, kv_row_offset: int = 0) -> torch.Tensor:
+    """Cross-attention. q: [images*tokens, C]; kv: [kv_batches*kv_rows_per_batch, 2C] (k | v).
+    Image z uses kv batch z // frames_per_kv, rows [kv_row_offset, kv_row_offset + kv_tokens)."""
+    c = q.shape[1]
+    d = c // heads
+    if out is None:
+        out = torch.empty_like(q)
+    ldk = kv.stride(0)
+    attention_raw(q, kv, kv, out, q_off=0, k_off=kv_row_offset * ldk, v_off=kv_row_offset * ldk + c, o_off=0,
+                  q_strides=(tokens * q.stride(0), 0, q.stride(0)), o_strides=(tokens * out.stride(0), 0, out.stride(0)),
+                  k_strides=(kv_rows_per_batch * ldk, 0, ldk), inner_count=1, kv_inner_count=1,
+                  kv_div=frames_per_kv, batches=images, heads=heads, head_dim=d, nq=tokens, nk=kv_tokens,
+                  scale=d ** -0.5, out_scale=out_scale, accumulate=accumulate)
+    return out
+
+
+def attention_temporal(qkv: torch.Tensor, b: int, frames: int, tokens: int, heads: int) -> torch.Tensor:
+    """Attention over the frame axis. qkv rows are in (b f n) order: [b*frames*tokens, 3C]."""
+    c = qkv.shape[1] // 3
+    d = c // heads
+    o = torch.empty((b * frames * tokens, c), device=qkv.device, dtype=qkv.dtype)
+    ld = qkv.stride(0)
+    attention_raw(qkv, qkv, qkv, o, q_off=0, k_off=c, v_off=2 * c, o_off=0,
+                  q_strides=(frames * tokens * ld, ld, tokens * ld), o_strides=(frames * tokens * c, c, tokens * c),
+                  k_strides=(frames * tokens * ld, ld, tokens * ld), inner_count=tokens, kv_inner_count=tokens,
+                  kv_div=1, batches=b * tokens, heads=heads, head_dim=d, nq=frames, nk=frames, scale=d ** -0.5)
+    return o
+
+
+def add_bcast(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a + b where b is tiled along the leading dimension (b.numel() divides a.numel())."""
+    _req_cuda(a, b)
+    assert a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.numel() % b.numel() == 0
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().ca_add_bcast(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), b.numel(), dt_code(a.dtype),
+                             _stream()), "ca_add_bcast")
+    return out
+
+
+def silu_f32(x: torch.Tensor) -> torch.Tensor:
+    _req_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty_like(x)
+    check(lib().ca_silu_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "ca_silu_f32")
+    return y
+
+
+def timestep_embedding(t, batch: int, dim: int, dtype: torch.dtype, device) -> torch.Tensor:
+    """t: python number (same for the whole batch) or fp32 device tensor [batch]."""
+    out = torch.empty((batch, dim), device=device, dtype=dtype)
+    if isinstance(t, torch.Tensor):
+        _req_cuda(t)
+        assert t.dtype == torch.float32 and t.numel() == batch
+        check(lib().ca_timestep_embedding(t.data_ptr(), 0.0, out.data_ptr(), batch, dim, dt_code(dtype), _stream()),
+              "ca_timestep_embedding")
+    else:
+        check(lib().ca_timestep_embedding(None, float(t), out.data_ptr(), batch, dim, dt_code(dtype), _stream()),
+              "ca_timestep_embedding")
+    return out
+
+
+def latents_to_nhwc(latents: torch.Tensor, cpad: int, rep: int, in_scale: float, dtype: torch.dtype) -> torch.Tensor:
+    _req_cuda(latents)
+    assert latents.dtype == torch.float32 and latents.is_contiguous() and latents.dim() == 5
+    b0, c, f, h, w = latents.shape
+    out = torch.empty((rep * b0 * f, h, w, cpad), device=latents.device, dtype=dtype)
+    check(lib().ca_latents_to_nhwc(latents.data_ptr(), out.data_ptr(), b0, c, f, h, w, cpad, rep, in_scale,
+                                   dt_code(dtype), _stream()), "ca_latents_to_nhwc")
+    return out
+
+
+def nhwc_to_ncfhw_f32(x: torch.Tensor, b: int, c: int, f: int) -> torch.Tensor:
+    """x: [b*f, h, w, ldx] (act dtype or fp32) -> [b, c, f, h, w] fp32."""
+    _req_cuda(x)
+    assert x.dim() == 4 and x.is_contiguous()
+    _, h, w, ldx = x.shape
+    out = torch.empty((b, c, f, h, w), device=x.device, dtype=torch.float32)
+    is_f32 = x.dtype == torch.float32
+    check(lib().ca_nhwc_to_ncfhw_f32(x.data_ptr(), out.data_ptr(), b, c, f, h, w, ldx, int(is_f32),
+                                     CA_BF16 if is_f32 else dt_code(x.dtype), _stream()), "ca_nhwc_to_ncfhw_f32")
+    return out
+
+
+_KIND = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def ncfhw_to_nhwc(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
+    """x: [b, c, f, h, w] any strides, fp32/fp16/bf16 -> [b*f, h, w, cpad] `dtype` (zero padded)."""
+    _req_cuda(x)
+    assert x.dim() == 5 and x.dtype in _KIND
+    b, c, f, h, w = x.shape
+    out = torch.empty((b * f, h, w, cpad), device=x.device, dtype=dtype)
+    st = (C.c_int64 * 5)(*x.stride())
+    check(lib().ca_ncfhw_to_nhwc(x.data_ptr(), _KIND[x.dtype], st, out.data_ptr(), b, c, f, h, w, cpad,
+                                 dt_code(dtype), _stream()), "ca_ncfhw_to_nhwc")
+    return out
+
+
+def cfg_scheduler_step(eps: torch.Tensor, rep: int, guidance: float, latents: torch.Tensor,
+                       noise: Optional[torch.Tensor], coef, clip: float = 0.0, want_denoised: bool = False):
+    """eps: NHWC fp32 [rep*f, h, w, ld]; latents/noise: [1, c, f, h, w] fp32. Returns (prev, denoised|None)."""
+    _req_cuda(eps, latents, noise)
+    assert eps.dtype == torch.float32 and eps.is_contiguous() and latents.dtype == torch.float32 and latents.is_contiguous()
+    _, c, f, h, w = latents.shape
+    assert latents.shape[0] == 1 and eps.shape[0] == rep * f
+    if noise is not None:
+        assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == latents.shape
+    prev = torch.empty_like(latents)
+    den = torch.empty_like(latents) if want_denoised else None
+    cf = (C.c_float * 7)(*[float(v) for v in coef])
+    check(lib().ca_cfg_scheduler_step(eps.data_ptr(), eps.shape[3], rep, float(guidance), latents.data_ptr(),
+                                      _p(noise), prev.data_ptr(), _p(den), c, f, h, w, cf, float(clip), _stream()),
+          "ca_cfg_scheduler_step")
+    return prev, den

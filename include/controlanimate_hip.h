@@ -1,0 +1,275 @@
+/*
+ * controlanimate_hip.h -- C ABI of the MI355X (gfx950) denoising-loop kernels.
+ *
+ * The reference (intellerce/controlanimate) has NO native/FFI boundary: its hot path is
+ * Python calling torch/cuDNN/cuBLAS/xformers ops.  This header is therefore the boundary
+ * a maintainer would bind UNDER the reference's Python modules (see INTEGRATION.md for the
+ * ctypes stub).  Each entry point names the reference call site(s) it replaces.
+ *
+ * Conventions:
+ *   - plain C, extern "C"; plain pointers and sizes; no torch / C++ types.
+ *   - all pointers are DEVICE pointers on the current HIP device; the caller owns every
+ *     buffer (kernels never allocate or free; scratch is passed in).
+ *   - every call is asynchronous on the `stream` argument (a hipStream_t passed as void*).
+ *   - returns CA_OK (0) or a negative CA_ERR_* code; never throws, never exits.
+ *     ca_last_error() returns a thread-local message for the last failing call.
+ *   - activations are channels-last: [images, H, W, C] (images = b*f in (b f) order),
+ *     element type `dtype` = CA_BF16 or CA_F16; accumulation is always fp32.
+ *   - "rows" means pixels/tokens: rows = images*H*W.
+ */
+#ifndef CONTROLANIMATE_HIP_H
+#define CONTROLANIMATE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CA_ABI_VERSION 1
+
+/* element types */
+#define CA_BF16 0
+#define CA_F16 1
+
+/* error codes */
+#define CA_OK 0
+#define CA_ERR_INVALID_ARG (-1)
+#define CA_ERR_UNSUPPORTED (-2)
+#define CA_ERR_LAUNCH (-3)
+
+/* epilogue activations */
+#define CA_ACT_NONE 0
+#define CA_ACT_SILU 1
+
+int ca_abi_version(void);
+const char* ca_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * ca_gemm: C[M,N] = epilogue( A[M,K] * W[N,K]^T )        (MFMA 16x16x32, fp32 accumulate)
+ *
+ * Replaces: every nn.Linear / 1x1 conv on the path --
+ *   diffusers Attention.to_q/to_k/to_v/to_out (animatediff/models/attention.py:206-285 via
+ *   modules/attention_processor.py:233-262), GEGLU.proj + ff.net[2]
+ *   (animatediff/models/attention.py:303-357), Transformer3DModel.proj_in/proj_out
+ *   (animatediff/models/attention.py:90,118), motion-module proj_in/proj_out
+ *   (animatediff/models/motion_module.py:112,134), ResnetBlock3D.time_emb_proj and
+ *   conv_shortcut (animatediff/models/resnet.py:163,186), TimestepEmbedding
+ *   (animatediff/models/unet.py:526-534), ControlNet zero-convs.
+ *
+ * A may be the channel-concatenation of two sources (a2 != NULL): columns [0,k1) come from
+ * `a` and [k1,k1+k2) from `a2` (replaces torch.cat at animatediff/models/unet_blocks.py:636,742
+ * for the shortcut conv).  K = k1 + k2.
+ *
+ * epilogue, per element (m,n), v = acc:
+ *   v += bias[n]                      (bias fp32 or NULL)
+ *   v += rowbias[(m / rows_per_group) * ld_rowbias + n]   (fp32 or NULL; time-embedding add,
+ *                                      animatediff/models/resnet.py:199-200)
+ *   v *= alpha
+ *   v += residual[m*ld_res + n]       (dtype or NULL; residual adds attention.py:273,285,288;
+ *                                      motion_module.py:218-222; resnet.py:216)
+ *   v *= post_scale                   (1/output_scale_factor, resnet.py:216)
+ *   v = act(v)
+ *   if geglu: weight rows are interleaved (h0,g0,h1,g1,...); out[m, n/2] = h * gelu_erf(g)
+ *             (diffusers GEGLU); C then has N/2 columns.
+ *   out_f32: store fp32 instead of dtype.
+ * Requirements: K1, K2, N multiples of 8 (N multiple of 4 allowed when N < 8), lda/ldc/ld_res
+ * multiples of 8 (dtype) so that 16-byte accesses are aligned.
+ * ------------------------------------------------------------------------------------ */
+typedef struct ca_gemm_args {
+  const void* a;        /* [M, k1] rows at stride lda            */
+  const void* a2;       /* [M, k2] rows at stride lda2, or NULL  */
+  const void* w;        /* [N, K] row-major (PyTorch Linear.weight layout), dtype */
+  void* c;              /* [M, N or N/2]                          */
+  const float* bias;    /* [N] fp32 or NULL                       */
+  const float* rowbias; /* [ceil(M/rows_per_group), ld_rowbias] fp32 or NULL */
+  const void* residual; /* [M, N] dtype or NULL                   */
+  int64_t lda, lda2, ldc, ld_res, ld_rowbias;
+  int32_t m, n, k1, k2;
+  int32_t rows_per_group;
+  float alpha, post_scale;
+  int32_t act;          /* CA_ACT_*      */
+  int32_t geglu;        /* 0/1           */
+  int32_t out_f32;      /* 0/1           */
+  int32_t dtype;        /* CA_BF16/CA_F16 */
+} ca_gemm_args;
+int ca_gemm(const ca_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ca_conv3x3: NHWC 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM
+ *   (M = images*Hout*Wout, N = Cout, K = 9*Cin) on the same MFMA core as ca_gemm.
+ *
+ * Replaces: InflatedConv3d (animatediff/models/resnet.py:12-20) at conv_in/conv_out
+ *   (unet.py:140,319), ResnetBlock3D.conv1/conv2 (resnet.py:153,173), Downsample3D
+ *   (resnet.py:96, stride 2), Upsample3D (resnet.py:47,67: `upsample`=1 folds the nearest x2
+ *   F.interpolate into the input gather), ControlNet convs and hint embedding.
+ * Input may be the channel concat of two NHWC sources (x2 != NULL).
+ * Weight layout: [Cout][kh][kw][Cin] (packed once at load from PyTorch's [Cout][Cin][kh][kw]).
+ * Epilogue fields as in ca_gemm (rowbias = time embedding per batch element b:
+ *   rows_per_group = f*Hout*Wout; residual = shortcut input).
+ * Hin/Win are the dimensions of the STORED input; with upsample=1 the logical input is
+ * 2*Hin x 2*Win.  Cin1, Cin2, Cout multiples of 8 (Cout multiple of 4 when < 8).
+ * ------------------------------------------------------------------------------------ */
+typedef struct ca_conv_args {
+  const void* x;        /* [images, Hin, Win, cin1] */
+  const void* x2;       /* [images, Hin, Win, cin2] or NULL */
+  const void* w;        /* [cout, 3, 3, cin1+cin2] */
+  void* y;              /* [images, Hout, Wout, cout] */
+  const float* bias;
+  const float* rowbias;
+  const void* residual; /* [images*Hout*Wout, ld_res] */
+  int64_t ld_res, ld_rowbias;
+  int32_t images, hin, win, cin1, cin2, cout;
+  int32_t stride;       /* 1 or 2 */
+  int32_t upsample;     /* 0 or 1 (nearest x2 before the conv) */
+  int32_t rows_per_group;
+  float alpha, post_scale;
+  int32_t act;
+  int32_t out_f32;
+  int32_t dtype;
+} ca_conv_args;
+int ca_conv3x3(const ca_conv_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU), NHWC, two launches: statistics then apply.
+ *
+ * Replaces: InflatedGroupNorm / nn.GroupNorm + SiLU (animatediff/models/resnet.py:23-31,
+ *   148-151,169-170,191-192,202,208; unet.py:316-317,614-615), GroupNorm eps=1e-6 without
+ *   activation (animatediff/models/attention.py:86,130; motion_module.py:111,144).
+ * `frames_per_stat` = 1 gives per-frame statistics (InflatedGroupNorm / v2); = f gives the
+ * cross-frame statistics of plain nn.GroupNorm on the 5-D tensor (v1 motion module configs,
+ * SURVEY App. C-5).  Input may be a channel concat of two sources.
+ *
+ * ca_groupnorm_stats writes partial (sum, sumsq) per (stat group, row chunk, norm group)
+ * into `partials` (fp32, ca_groupnorm_partials_floats() elements); ca_groupnorm_apply
+ * reduces the partials deterministically (fixed order, fp64 combine) and normalises.
+ * ------------------------------------------------------------------------------------ */
+typedef struct ca_groupnorm_args {
+  const void* x;        /* [images, hw, c1] */
+  const void* x2;       /* [images, hw, c2] or NULL */
+  void* y;              /* [images, hw, c1+c2] */
+  const float* gamma;   /* [c1+c2] */
+  const float* beta;    /* [c1+c2] */
+  float* partials;      /* scratch, see ca_groupnorm_partials_floats */
+  int32_t images, hw, c1, c2;
+  int32_t groups;       /* 32 */
+  int32_t frames_per_stat;
+  float eps;
+  int32_t act;          /* CA_ACT_NONE / CA_ACT_SILU */
+  int32_t dtype;
+} ca_groupnorm_args;
+int64_t ca_groupnorm_partials_floats(int32_t images, int32_t hw, int32_t frames_per_stat, int32_t groups);
+int ca_groupnorm_stats(const ca_groupnorm_args* args, void* stream);
+int ca_groupnorm_apply(const ca_groupnorm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ca_layernorm: y[r,:] = LN(x[r,:]) * gamma + beta (+ pos[(r / rows_per_frame) % frames, :])
+ *
+ * Replaces: nn.LayerNorm in BasicTransformerBlock (animatediff/models/attention.py:214,231,237)
+ *   and TemporalTransformerBlock (motion_module.py:203,209); the optional `pos` table fuses
+ *   PositionalEncoding.forward (motion_module.py:243-245: x + pe[:, :f]) -- rows are in
+ *   (b f n) order so the frame of row r is (r / rows_per_frame) % frames.
+ * eps = 1e-5 (torch default). C multiple of 8, C <= 2048.
+ * ------------------------------------------------------------------------------------ */
+typedef struct ca_layernorm_args {
+  const void* x; void* y;
+  const float* gamma; const float* beta;
+  const float* pos;     /* [frames, c] fp32 or NULL */
+  int64_t rows;
+  int32_t c;
+  int32_t rows_per_frame, frames;
+  float eps;
+  int32_t dtype;
+} ca_layernorm_args;
+int ca_layernorm(const ca_layernorm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ca_attention: O = softmax(Q K^T * scale) V per (batch z, head), flash-style online softmax,
+ *   MFMA for QK^T and PV.  One kernel serves:
+ *   - spatial self-attention  (AttnProcessor2_0, modules/attention_processor.py:200-272;
+ *     called from animatediff/models/attention.py:271)
+ *   - cross-attention with per-b text K/V shared by the f frames of b (kv_div = f; replaces the
+ *     `repeat 'b n c -> (b f) n c'` at animatediff/models/attention.py:125) incl. the
+ *     ControlNet variant that drops the last 4 tokens (CNAttnProcessor2_0, :608-609: pass nk-4)
+ *   - IP-Adapter's second attention over the 4 image tokens, accumulated into O
+ *     (IPAttnProcessor2_0, modules/attention_processor.py:461-477): accumulate=1, out_scale=scale
+ *   - temporal self-attention over frames (VersatileAttention, animatediff/models/
+ *     motion_module.py:272-329): the `(b f) d c -> (b d) f c` transposes are replaced by
+ *     strided addressing (row_stride = tokens*ld, inner = tokens).
+ *
+ * Addressing (element offsets): for batch z (0 <= z < batches):
+ *   zo = z / inner_count, zi = z % inner_count
+ *   Q row i  at q + zo*q_outer + zi*q_inner + i*q_row + head*head_dim   (same scheme for O)
+ *   z' = z / kv_div; K row j at k + (z'/kv_inner_count)*k_outer + (z'%kv_inner_count)*k_inner
+ *                                   + j*k_row + head*head_dim   (same for V with v pointer)
+ * head_dim multiple of 8, <= 160.
+ * ------------------------------------------------------------------------------------ */
+typedef struct ca_attn_args {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t q_outer, q_inner, q_row;
+  int64_t o_outer, o_inner, o_row;
+  int64_t k_outer, k_inner, k_row;   /* shared by K and V */
+  int32_t inner_count, kv_inner_count, kv_div;
+  int32_t batches, heads, head_dim;
+  int32_t nq, nk;
+  float scale;          /* softmax scale (head_dim^-0.5) */
+  float out_scale;      /* multiplies the attention output */
+  int32_t accumulate;   /* 1: O += out_scale * attn */
+  int32_t dtype;
+} ca_attn_args;
+int ca_attention(const ca_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small elementwise kernels of the loop.
+ * ------------------------------------------------------------------------------------ */
+
+/* out[i] = a[i] + b[i % b_period]  (dtype).  ControlNet residual adds incl. the broadcast of
+ * b=1 residuals over the CFG batch (animatediff/models/unet.py:567-576,584-585). n multiple of 8. */
+int ca_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t b_period,
+                 int32_t dtype, void* stream);
+
+/* y = silu(x) on fp32 vectors (ResnetBlock3D: time_emb_proj(silu(temb)), resnet.py:196). */
+int ca_silu_f32(const float* x, float* y, int64_t n, void* stream);
+
+/* Timesteps(320, flip_sin_to_cos=True, freq_shift=0) (unet.py:526):
+ * out[b, :] = [cos(t*f_i), sin(t*f_i)], f_i = exp(-ln(10000)*i/half); out dtype for the
+ * following linear_1 GEMM. `t` per batch element in a device fp32 array or (t_dev NULL) the
+ * scalar t_host. */
+int ca_timestep_embedding(const float* t_dev, float t_host, void* out, int32_t batch,
+                          int32_t dim, int32_t dtype, void* stream);
+
+/* latents [b0, c, f, h, w] fp32 -> UNet input NHWC [rep*b0*f, h, w, cpad] dtype, multiplied by
+ * in_scale (scheduler.scale_model_input) and duplicated `rep` times for CFG
+ * (controlanimation_pipeline.py:797-800).  Channels c..cpad-1 are zero. */
+int ca_latents_to_nhwc(const float* latents, void* out, int32_t b0, int32_t c, int32_t f,
+                       int32_t h, int32_t w, int32_t cpad, int32_t rep, float in_scale,
+                       int32_t dtype, void* stream);
+
+/* UNet output NHWC [b*f, h, w, c] (dtype or fp32) -> [b, c, f, h, w] fp32 (API boundary). */
+int ca_nhwc_to_ncfhw_f32(const void* x, float* out, int32_t b, int32_t c, int32_t f, int32_t h,
+                         int32_t w, int32_t ldx, int32_t x_is_f32, int32_t dtype, void* stream);
+
+/* generic layout converters at the module API boundary:
+ * [b, c, f, h, w] (fp32 | fp16 | bf16, arbitrary strides given in elements) <-> NHWC dtype. */
+int ca_ncfhw_to_nhwc(const void* x, int32_t x_kind /*0 f32,1 f16,2 bf16*/, const int64_t strides[5],
+                     void* out, int32_t b, int32_t c, int32_t f, int32_t h, int32_t w, int32_t cpad,
+                     int32_t dtype, void* stream);
+
+/* Fused classifier-free-guidance combine + scheduler update
+ * (controlanimation_pipeline.py:844-849 and the step functions :1520-1609 / diffusers
+ * DDIM/LCM/Euler restated in oracle/schedulers.py).  eps comes NHWC fp32 [rep*f, h, w, ld_eps]
+ * from conv_out; latents/noise/prev/denoised are [1, c, f, h, w] fp32.
+ *   eps  = rep==2 ? e_u + g*(e_c - e_u) : e
+ *   x0   = (x - coef[0]*eps) * coef[1];  if clip > 0: x0 = clamp(x0, -clip, clip)
+ *   den  = coef[2]*x0 + coef[3]*x
+ *   prev = coef[4]*den + coef[5]*eps + coef[6]*noise
+ * `noise` / `denoised` may be NULL. */
+int ca_cfg_scheduler_step(const float* eps, int32_t ld_eps, int32_t rep, float guidance,
+                          const float* latents, const float* noise, float* prev, float* denoised,
+                          int32_t c, int32_t f, int32_t h, int32_t w, const float coef[7],
+                          float clip, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTROLANIMATE_HIP_H */

@@ -1,0 +1,395 @@
+"""Kernel-level parity: every C-ABI entry point vs a plain torch fp32 reference of the same op.
+
+Inputs are rounded to the activation dtype first, so the only differences are fp32-accumulation
+order and the final rounding of the output (bf16: 2^-9 relative).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def _k():
+    from controlanimate_amd import kernels
+    return kernels
+
+
+def rnd(*shape, dtype=torch.bfloat16, scale=1.0, seed=None):
+    g = torch.Generator().manual_seed(seed if seed is not None else (hash(shape) % 100003))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def close(out, ref, dtype, what, rel=None):
+    out = out.float().cpu()
+    ref = ref.float()
+    assert out.shape == ref.shape, f"{what}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10
+    rel = rel if rel is not None else 2.5 * eps
+    err = (out - ref).abs()
+    denom = ref.abs().max().clamp_min(1e-6)
+    rel_l2 = (out - ref).norm() / ref.norm().clamp_min(1e-12)
+    max_rel = (err.max() / denom).item()
+    assert rel_l2.item() < rel and max_rel < 4 * rel, f"{what}: rel_l2={rel_l2.item():.3e} max_err/max_ref={max_rel:.3e} (tol {rel:.1e})"
+
+
+# ------------------------------------------------------------------------------------ GEMM
+GEMM_CASES = [
+    # m, n, k1, k2, bias, rowbias, residual, alpha, post, act, geglu, out_f32
+    (256, 128, 64, 0, False, False, False, 1.0, 1.0, 0, False, False),
+    (200, 320, 320, 0, True, False, True, 1.0, 1.0, 0, False, False),
+    (130, 24, 40, 0, True, False, False, 1.0, 1.0, 0, False, False),
+    (512, 640, 320, 0, True, True, True, 0.5, 0.7, 1, False, False),
+    (300, 256, 64, 0, True, False, False, 1.0, 1.0, 0, True, False),
+    (300, 2560, 320, 0, True, False, False, 1.0, 1.0, 0, True, False),
+    (256, 320, 320, 640, True, False, False, 1.0, 1.0, 0, False, False),
+    (2, 1280, 320, 0, True, False, False, 1.0, 1.0, 1, False, True),
+    (154, 640, 768, 0, False, False, False, 1.0, 1.0, 0, False, False),
+    (4096, 1280, 1280, 0, True, False, True, 1.0, 1.0, 0, False, False),
+    (1000, 8, 64, 0, True, False, False, 1.0, 1.0, 0, False, False),
+    (77, 4, 32, 0, False, False, False, 1.0, 1.0, 0, False, True),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm(case, dtype):
+    k = _k()
+    m, n, k1, k2, has_bias, has_rb, has_res, alpha, post, act, geglu, out_f32 = case
+    a = rnd(m, k1, dtype=dtype, seed=1)
+    a2 = rnd(m, k2, dtype=dtype, seed=2) if k2 else None
+    w = rnd(n, k1 + k2, dtype=dtype, scale=(k1 + k2) ** -0.5, seed=3)
+    bias = rnd(n, dtype=torch.float32, seed=4) if has_bias else None
+    rpg = 64
+    rb = rnd((m + rpg - 1) // rpg, n, dtype=torch.float32, seed=5) if has_rb else None
+    res = rnd(m, n, dtype=dtype, seed=6) if has_res else None
+    acat = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
+    ref = acat @ w.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if rb is not None:
+        ref = ref + rb[torch.arange(m) // rpg]
+    ref = ref * alpha
+    if res is not None:
+        ref = ref + res.float()
+    ref = ref * post
+    if act == 1:
+        ref = F.silu(ref)
+    if geglu:
+        ref = ref[:, 0::2] * F.gelu(ref[:, 1::2])
+    out = k.gemm(a.to(DEV), w.to(DEV), a2=None if a2 is None else a2.to(DEV),
+                 bias=None if bias is None else bias.to(DEV), rowbias=None if rb is None else rb.to(DEV),
+                 rows_per_group=rpg if has_rb else 0, residual=None if res is None else res.to(DEV),
+                 alpha=alpha, post_scale=post, act=act, geglu=geglu, out_f32=out_f32)
+    torch.cuda.synchronize()
+    assert out.dtype == (torch.float32 if out_f32 else dtype)
+    close(out, ref, dtype, f"gemm{case}")
+
+
+def test_gemm_strided_views():
+    """lda/ldc larger than the logical width (column slices of a wider buffer)."""
+    k = _k()
+    dtype = torch.bfloat16
+    big = rnd(300, 960, dtype=dtype, seed=7).to(DEV)
+    w = rnd(320, 320, dtype=dtype, scale=320 ** -0.5, seed=8).to(DEV)
+    a = big[:, 320:640]
+    outbuf = torch.zeros(300, 640, device=DEV, dtype=dtype)
+    out = outbuf[:, 320:]
+    k.gemm(a, w, out=out)
+    torch.cuda.synchronize()
+    close(out, a.float().cpu() @ w.float().cpu().t(), dtype, "gemm strided")
+    assert outbuf[:, :320].abs().max().item() == 0
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric W catches a transposed C write."""
+    k = _k()
+    dtype = torch.bfloat16
+    n, kk = 192, 128
+    a = torch.eye(kk, dtype=dtype)
+    w = (torch.arange(n)[:, None] * 0.01 + torch.arange(kk)[None, :] * 0.0001).to(dtype)
+    out = k.gemm(a.to(DEV), w.to(DEV))
+    torch.cuda.synchronize()
+    close(out, w.float().t(), dtype, "gemm identity")
+
+
+def test_gemm_rejects_bad_args():
+    k = _k()
+    from controlanimate_amd._capi import CAHipError
+    a = rnd(16, 12, seed=1).to(DEV)  # K not a multiple of 8
+    w = rnd(16, 12, seed=2).to(DEV)
+    with pytest.raises(CAHipError):
+        k.gemm(a, w)
+
+
+# ------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # images, h, w, cin1, cin2, cout, stride, upsample, bias, rowbias, residual, act, out_f32
+    (2, 16, 16, 32, 0, 64, 1, False, True, False, False, 0, False),
+    (2, 16, 16, 64, 0, 64, 2, False, True, False, False, 0, False),
+    (3, 10, 6, 32, 0, 32, 1, False, True, True, True, 0, False),
+    (3, 9, 7, 32, 0, 32, 2, False, True, False, False, 0, False),
+    (2, 8, 8, 64, 0, 64, 1, True, True, False, False, 0, False),
+    (2, 8, 8, 64, 32, 128, 1, False, True, True, True, 0, False),
+    (4, 16, 16, 8, 0, 320, 1, False, True, False, False, 0, False),
+    (4, 16, 16, 320, 0, 4, 1, False, True, False, False, 0, True),
+    (2, 32, 32, 8, 0, 16, 1, False, True, False, False, 1, False),
+    (2, 16, 16, 96, 0, 256, 2, False, True, False, False, 1, False),
+    (2, 8, 8, 1280, 1280, 1280, 1, False, True, True, False, 0, False),
+    (8, 32, 32, 320, 0, 320, 1, False, True, True, True, 0, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3(case, dtype):
+    k = _k()
+    images, h, w_, c1, c2, cout, stride, ups, has_bias, has_rb, has_res, act, out_f32 = case
+    cin = c1 + c2
+    x = rnd(images, h, w_, c1, dtype=dtype, seed=11)
+    x2 = rnd(images, h, w_, c2, dtype=dtype, seed=12) if c2 else None
+    wt = rnd(cout, cin, 3, 3, dtype=dtype, scale=(9 * cin) ** -0.5, seed=13)  # torch OIHW
+    bias = rnd(cout, dtype=torch.float32, seed=14) if has_bias else None
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], -1)
+    xin = xin.permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, wt.float(), bias, stride=stride, padding=1)
+    hout, wout = ref.shape[2:]
+    frames = 1 if images % 2 else 2  # rowbias per batch element: images = b * frames
+    rpg = frames * hout * wout
+    rb = rnd(images // frames, cout, dtype=torch.float32, seed=15) if has_rb else None
+    if rb is not None:
+        ref = ref + rb.repeat_interleave(frames, 0)[:, :, None, None]
+    res = rnd(images, hout, wout, cout, dtype=dtype, seed=16) if has_res else None
+    if res is not None:
+        ref = (ref + res.float().permute(0, 3, 1, 2)) * 0.5
+    if act == 1:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    out = k.conv3x3(x.to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), x2=None if x2 is None else x2.to(DEV),
+                    bias=None if bias is None else bias.to(DEV), rowbias=None if rb is None else rb.to(DEV),
+                    rows_per_group=rpg if has_rb else 0, residual=None if res is None else res.to(DEV),
+                    stride=stride, upsample=ups, post_scale=0.5 if has_res else 1.0, act=act, out_f32=out_f32)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, f"conv{case}")
+
+
+# ------------------------------------------------------------------------------------ norms
+GN_CASES = [
+    # images, h, w, c1, c2, frames_per_stat, act, eps
+    (4, 8, 8, 320, 0, 1, 1, 1e-5),
+    (4, 8, 8, 320, 0, 2, 1, 1e-5),
+    (2, 16, 16, 32, 0, 1, 0, 1e-6),
+    (2, 5, 7, 64, 0, 1, 0, 1e-6),
+    (2, 8, 8, 1280, 1280, 1, 1, 1e-5),
+    (2, 8, 8, 640, 320, 2, 1, 1e-5),
+    (16, 64, 64, 320, 0, 1, 1, 1e-5),
+    (8, 32, 32, 320, 0, 8, 1, 1e-5),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", GN_CASES)
+def test_groupnorm(case, dtype):
+    k = _k()
+    images, h, w_, c1, c2, fps, act, eps = case
+    c = c1 + c2
+    x = (rnd(images, h, w_, c1, dtype=torch.float32, seed=21) * 1.5 + 0.3).to(dtype)
+    x2 = (rnd(images, h, w_, c2, dtype=torch.float32, seed=22) * 0.7 - 0.2).to(dtype) if c2 else None
+    gamma = rnd(c, dtype=torch.float32, seed=23) * 0.2 + 1.0
+    beta = rnd(c, dtype=torch.float32, seed=24) * 0.2
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], -1)
+    # [images, h, w, c] -> [images/fps, c, fps, h, w]: stats span fps frames
+    x5 = xin.reshape(images // fps, fps, h, w_, c).permute(0, 4, 1, 2, 3)
+    ref = F.group_norm(x5, 32, gamma, beta, eps)
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(images, h, w_, c)
+    out = k.group_norm(x.to(DEV), gamma.to(DEV), beta.to(DEV), x2=None if x2 is None else x2.to(DEV),
+                       frames_per_stat=fps, eps=eps, act=act)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, f"groupnorm{case}")
+
+
+def test_groupnorm_deterministic():
+    k = _k()
+    x = rnd(8, 32, 32, 320, seed=25).to(DEV)
+    g = torch.ones(320, device=DEV)
+    b = torch.zeros(320, device=DEV)
+    o1 = k.group_norm(x, g, b, act=1)
+    o2 = k.group_norm(x, g, b, act=1)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,c,frames,rpf", [(100, 320, 0, 0), (64, 1280, 0, 0), (33, 32, 0, 0), (2 * 16 * 12, 640, 16, 12),
+                                               (5000, 320, 8, 125)])
+def test_layernorm(rows, c, frames, rpf, dtype):
+    k = _k()
+    x = (rnd(rows, c, dtype=torch.float32, seed=31) * 2 + 0.5).to(dtype)
+    gamma = rnd(c, dtype=torch.float32, seed=32) * 0.2 + 1.0
+    beta = rnd(c, dtype=torch.float32, seed=33) * 0.2
+    ref = F.layer_norm(x.float(), (c,), gamma, beta, 1e-5)
+    pos = None
+    if frames:
+        pos = rnd(frames, c, dtype=torch.float32, seed=34)
+        fr = (torch.arange(rows) // rpf) % frames
+        ref = ref + pos[fr]
+    out = k.layer_norm(x.to(DEV), gamma.to(DEV), beta.to(DEV), pos=None if pos is None else pos.to(DEV),
+                       rows_per_frame=rpf or 1, frames=frames or 1)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, f"layernorm({rows},{c},{frames})")
+
+
+# ------------------------------------------------------------------------------------ attention
+def _sdpa(q, k_, v):  # [B, H, N, d] fp32
+    s = (q @ k_.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("images,tokens,heads,d", [(2, 256, 8, 40), (2, 100, 8, 80), (1, 64, 8, 160), (3, 16, 4, 8),
+                                                  (2, 4, 8, 16), (2, 1, 8, 32), (1, 1024, 8, 40), (1, 300, 2, 64),
+                                                  (1, 200, 2, 128), (2, 144, 8, 160)])
+def test_attention_spatial(images, tokens, heads, d, dtype):
+    k = _k()
+    c = heads * d
+    qkv = rnd(images * tokens, 3 * c, dtype=dtype, seed=41)
+    q, kk, v = [t.float().reshape(images, tokens, heads, d).transpose(1, 2) for t in qkv.split(c, dim=1)]
+    ref = _sdpa(q, kk, v).transpose(1, 2).reshape(images * tokens, c)
+    out = k.attention_spatial(qkv.to(DEV), images, tokens, heads)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, f"attn_spatial({images},{tokens},{heads},{d})", rel=8e-3 if dtype == torch.bfloat16 else 3e-3)
+
+
+def test_attention_online_softmax_rescale():
+    """A spiked key in a LATER kv block forces the running-max rescale branch."""
+    k = _k()
+    dtype = torch.bfloat16
+    images, tokens, heads, d = 1, 256, 1, 64
+    c = heads * d
+    qkv = rnd(images * tokens, 3 * c, dtype=dtype, seed=42).float()
+    qkv[200, c:2 * c] = qkv[3, 0:c] * 6.0  # key 200 aligned with query 3
+    qkv[70, c:2 * c] = qkv[9, 0:c] * 4.0
+    qkv = qkv.to(dtype)
+    q, kk, v = [t.float().reshape(images, tokens, heads, d).transpose(1, 2) for t in qkv.split(c, dim=1)]
+    ref = _sdpa(q, kk, v).transpose(1, 2).reshape(images * tokens, c)
+    out = k.attention_spatial(qkv.to(DEV), images, tokens, heads)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, "attn rescale", rel=8e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,f,tokens,heads,d,L,strip", [(2, 4, 64, 8, 40, 77, 0), (1, 3, 50, 8, 80, 81, 4), (2, 2, 16, 8, 160, 77, 0)])
+def test_attention_cross_and_ip(b, f, tokens, heads, d, L, strip, dtype):
+    k = _k()
+    c = heads * d
+    images = b * f
+    q = rnd(images * tokens, c, dtype=dtype, seed=43)
+    kv = rnd(b * L, 2 * c, dtype=dtype, seed=44)
+    nk = L - strip
+    qh = q.float().reshape(images, tokens, heads, d).transpose(1, 2)
+    kh = kv[:, :c].float().reshape(b, L, heads, d)[:, :nk].transpose(1, 2).repeat_interleave(f, 0)
+    vh = kv[:, c:].float().reshape(b, L, heads, d)[:, :nk].transpose(1, 2).repeat_interleave(f, 0)
+    ref = _sdpa(qh, kh, vh).transpose(1, 2).reshape(images * tokens, c)
+    out = k.attention_cross(q.to(DEV), kv.to(DEV), images, tokens, heads, nk, L, f)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, "attn_cross", rel=8e-3 if dtype == torch.bfloat16 else 3e-3)
+    if strip:
+        # IP-Adapter: second attention over the last `strip` rows of an ip K/V buffer, accumulated with a scale
+        kvip = rnd(b * strip, 2 * c, dtype=dtype, seed=45)
+        kh2 = kvip[:, :c].float().reshape(b, strip, heads, d).transpose(1, 2).repeat_interleave(f, 0)
+        vh2 = kvip[:, c:].float().reshape(b, strip, heads, d).transpose(1, 2).repeat_interleave(f, 0)
+        ref2 = out.float().cpu() + 0.4 * _sdpa(qh, kh2, vh2).transpose(1, 2).reshape(images * tokens, c)
+        k.attention_cross(q.to(DEV), kvip.to(DEV), images, tokens, heads, strip, strip, f, out=out, out_scale=0.4,
+                          accumulate=True)
+        torch.cuda.synchronize()
+        close(out, ref2, dtype, "attn_ip_accumulate", rel=1e-2 if dtype == torch.bfloat16 else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,f,tokens,heads,d", [(2, 16, 20, 8, 40), (1, 8, 64, 8, 80), (2, 24, 9, 8, 160), (1, 32, 5, 8, 16), (2, 16, 256, 8, 40)])
+def test_attention_temporal(b, f, tokens, heads, d, dtype):
+    k = _k()
+    c = heads * d
+    qkv = rnd(b * f * tokens, 3 * c, dtype=dtype, seed=46)
+    # rows (b f n) -> per (b, n): sequence over f
+    t = qkv.float().reshape(b, f, tokens, 3, heads, d).permute(3, 0, 2, 4, 1, 5)  # [3, b, n, h, f, d]
+    ref = _sdpa(t[0], t[1], t[2])  # [b, n, h, f, d]
+    ref = ref.permute(0, 3, 1, 2, 4).reshape(b * f * tokens, c)
+    out = k.attention_temporal(qkv.to(DEV), b, f, tokens, heads)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, f"attn_temporal({b},{f},{tokens},{heads},{d})", rel=8e-3 if dtype == torch.bfloat16 else 3e-3)
+
+
+# ------------------------------------------------------------------------------------ elementwise
+def test_add_bcast():
+    k = _k()
+    a = rnd(2, 4, 8, 8, 64, seed=51)
+    b = rnd(1, 4, 8, 8, 64, seed=52)
+    out = k.add_bcast(a.to(DEV), b.to(DEV))
+    torch.cuda.synchronize()
+    close(out, a.float() + b.float(), torch.bfloat16, "add_bcast")
+
+
+def test_silu_and_timestep_embedding():
+    k = _k()
+    x = rnd(2, 1280, dtype=torch.float32, seed=53)
+    y = k.silu_f32(x.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.allclose(y.cpu(), F.silu(x), atol=1e-5, rtol=1e-5)
+    half = 160
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    for t in (999.0, 3.0):
+        emb = k.timestep_embedding(t, 2, 320, torch.bfloat16, DEV)
+        arg = t * freq
+        ref = torch.cat([torch.cos(arg), torch.sin(arg)])[None].repeat(2, 1)
+        torch.cuda.synchronize()
+        assert (emb.float().cpu() - ref).abs().max().item() < 6e-3
+    tt = torch.tensor([10.0, 500.0], device=DEV)
+    emb = k.timestep_embedding(tt, 2, 320, torch.float16, DEV)
+    ref = torch.stack([torch.cat([torch.cos(t * freq), torch.sin(t * freq)]) for t in (10.0, 500.0)])
+    torch.cuda.synchronize()
+    assert (emb.float().cpu() - ref).abs().max().item() < 2e-3
+
+
+def test_layout_kernels_and_scheduler_step():
+    k = _k()
+    lat = rnd(1, 4, 6, 8, 10, dtype=torch.float32, seed=54)
+    nh = k.latents_to_nhwc(lat.to(DEV), 8, 2, 0.5, torch.bfloat16)
+    torch.cuda.synchronize()
+    ref = (lat * 0.5).permute(0, 2, 3, 4, 1).reshape(6, 8, 10, 4)
+    ref = torch.cat([ref, torch.zeros(6, 8, 10, 4)], -1).repeat(2, 1, 1, 1)
+    close(nh, ref, torch.bfloat16, "latents_to_nhwc")
+    back = k.nhwc_to_ncfhw_f32(nh, 2, 4, 6)
+    torch.cuda.synchronize()
+    close(back[0:1], lat * 0.5, torch.bfloat16, "nhwc_to_ncfhw")
+    x5 = rnd(2, 320, 3, 4, 5, dtype=torch.float16, seed=55).to(DEV)
+    xv = x5.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)  # channels-last strides, 5-D logical
+    for src in (x5, xv, x5.float()):
+        o = k.ncfhw_to_nhwc(src, 320, torch.bfloat16)
+        torch.cuda.synchronize()
+        close(o, x5.float().cpu().permute(0, 2, 3, 4, 1).reshape(6, 4, 5, 320), torch.bfloat16, "ncfhw_to_nhwc")
+    # scheduler step
+    f, h, w = 6, 8, 10
+    eps = rnd(2 * f, h, w, 4, dtype=torch.float32, seed=56)
+    noise = rnd(1, 4, f, h, w, dtype=torch.float32, seed=57)
+    coef = [0.3, 1.7, 0.9, 0.1, 0.8, 0.2, 0.5]
+    g = 7.5
+    prev, den = k.cfg_scheduler_step(eps.to(DEV), 2, g, lat.to(DEV), noise.to(DEV), coef, clip=1.0, want_denoised=True)
+    torch.cuda.synchronize()
+    e = eps.reshape(2, f, h, w, 4).permute(0, 4, 1, 2, 3)
+    e = e[0:1] + g * (e[1:2] - e[0:1])
+    x0 = ((lat - coef[0] * e) * coef[1]).clamp(-1, 1)
+    dref = coef[2] * x0 + coef[3] * lat
+    pref = coef[4] * dref + coef[5] * e + coef[6] * noise
+    assert torch.allclose(den.cpu(), dref, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(prev.cpu(), pref, atol=1e-5, rtol=1e-5)
