@@ -76,7 +76,7 @@ class AttnArgs(C.Structure):
         ("q_outer", C.c_int64), ("q_inner", C.c_int64), ("q_row", C.c_int64),
         ("o_outer", C.c_int64), ("o_inner", C.c_int64), ("o_row", C.c_int64),
         ("k_outer", C.c_int64), ("k_inner", C.c_int64), ("k_row", C.c_int64),
-        ("inner_count", C.c_int32), ("kv_inner_count", C.c_int32), ("kv_div", C.c_int32),
+        ("inner_count", C.c_int32), ("kv_inner_count", C.c_int32), ("kv_div", C.c_int32), ("kv_mod", C.c_int32),
         ("batches", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("nq", C.c_int32), ("nk", C.c_int32),
         ("scale", C.c_float), ("out_scale", C.c_float),

@@ -1,0 +1,157 @@
+"""Attention module + attention processors on the HIP kernels.
+
+Keeps the reference's processor protocol (modules/attention_processor.py:395-402):
+    processor(attn, hidden_states[B,N,C], encoder_hidden_states=None, attention_mask=None, temb=None)
+with `attn` exposing to_q/to_k/to_v/to_out/heads/scale, and the same three processor kinds:
+    AttnProcessor2_0      plain SDPA attention                        (reference :186-272)
+    IPAttnProcessor2_0    + IP-Adapter K/V over the last 4 context tokens, out += scale*ip (:367-492)
+    CNAttnProcessor2_0    ControlNet variant that drops the last 4 context tokens          (:561-646)
+What differs is HOW they run: fused q|k|v (or k|v) GEMM -> flash attention kernel -> output
+projection with the residual add fused into its epilogue; text K/V are computed once per b (the
+reference repeats the prompt per frame, animatediff/models/attention.py:125) and cached across
+denoising steps while the caller keeps passing the same prompt tensor.
+`hidden_states` are device tensors in the activation dtype (bf16/fp16); there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from .layers import HipLinear, WeightArena, pack_concat_rows
+
+
+class AttnProcessor2_0(nn.Module):
+    """Default processor (self-, cross- and temporal attention)."""
+
+    num_tokens = 0       # context tokens reserved for IP-Adapter
+    drop_ip_tokens = False
+
+    def __init__(self, hidden_size=None, cross_attention_dim=None):
+        super().__init__()
+
+    def ip_branch(self, attn, q, ctx, out, images, tokens, kv_rows, frames_per_kv, kv_mod, cache):
+        return out
+
+    def __call__(self, attn: "Attention", hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
+                 attention_mask=None, temb=None, *, residual: Optional[torch.Tensor] = None, frames_per_kv: int = 1,
+                 kv_mod: int = 0, temporal=None, cache: Optional[dict] = None) -> torch.Tensor:
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is not used anywhere on the reference's path")
+        B, N, C = hidden_states.shape
+        x = hidden_states.reshape(B * N, C)
+        res = None if residual is None else residual.reshape(B * N, C)
+        if encoder_hidden_states is None:
+            qkv = K.gemm(x, attn.qkv.t)
+            if temporal is not None:
+                b, f, n = temporal
+                o = K.attention_temporal(qkv, b, f, n, attn.heads)
+            else:
+                o = K.attention_spatial(qkv, B, N, attn.heads)
+        else:
+            ctx = encoder_hidden_states
+            nb, L, cd = ctx.shape
+            q = K.gemm(x, attn.to_q.w.t)
+            kv = None if cache is None else cache.get(("kv", id(attn)))
+            if kv is None:
+                kv = K.gemm(ctx.reshape(nb * L, cd), attn.kv.t)
+                if cache is not None:
+                    cache[("kv", id(attn))] = kv
+            nk = L - self.num_tokens
+            o = K.attention_cross(q, kv, B, N, attn.heads, nk, L, frames_per_kv, kv_mod=kv_mod)
+            o = self.ip_branch(attn, q, ctx, o, B, N, L, frames_per_kv, kv_mod, cache)
+        out = attn.to_out[0].run(o, residual=res)
+        return out.reshape(B, N, C)
+
+
+class IPAttnProcessor2_0(AttnProcessor2_0):
+    """IP-Adapter processor: extra K/V projections for the image-prompt tokens."""
+
+    def __init__(self, hidden_size, cross_attention_dim=None, scale=1.0, num_tokens=4):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        self.scale = scale
+        self.num_tokens = num_tokens
+        self.to_k_ip = HipLinear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.to_v_ip = HipLinear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.kv_ip = None
+
+    def pack(self, arena: WeightArena, dtype):
+        self.kv_ip = pack_concat_rows(arena, dtype, [self.to_k_ip, self.to_v_ip])
+
+    def ip_branch(self, attn, q, ctx, out, images, tokens, kv_rows, frames_per_kv, kv_mod, cache):
+        if self.kv_ip is None:
+            raise RuntimeError("IPAttnProcessor2_0 installed after prepare(); call model.prepare() again")
+        nb, L, cd = ctx.shape
+        kvip = None if cache is None else cache.get(("kv_ip", id(self)))
+        if kvip is None:
+            kvip = K.gemm(ctx.reshape(nb * L, cd), self.kv_ip.t)  # all rows; only the last num_tokens are read
+            if cache is not None:
+                cache[("kv_ip", id(self))] = kvip
+        return K.attention_cross(q, kvip, images, tokens, attn.heads, self.num_tokens, L, frames_per_kv, out=out,
+                                 out_scale=float(self.scale), accumulate=True, kv_row_offset=L - self.num_tokens,
+                                 kv_mod=kv_mod)
+
+
+class CNAttnProcessor2_0(AttnProcessor2_0):
+    """ControlNet processor under IP-Adapter: only the text part of the context is used."""
+
+    def __init__(self, num_tokens=4):
+        super().__init__()
+        self.num_tokens = num_tokens
+
+
+# reference aliases (modules/ip_adapter.py:22-25 picks the 2_0 classes when torch has SDPA)
+AttnProcessor = AttnProcessor2_0
+IPAttnProcessor = IPAttnProcessor2_0
+CNAttnProcessor = CNAttnProcessor2_0
+
+
+class Attention(nn.Module):
+    """diffusers-style Attention block: bias-free q/k/v projections, biased output projection."""
+
+    def __init__(self, query_dim: int, cross_attention_dim: Optional[int] = None, heads: int = 8, dim_head: int = 64,
+                 dropout: float = 0.0, bias: bool = False, upcast_attention: bool = False, processor=None, **_):
+        super().__init__()
+        inner = heads * dim_head
+        self.is_cross = cross_attention_dim is not None
+        ctx_dim = cross_attention_dim if self.is_cross else query_dim
+        self.query_dim, self.cross_attention_dim, self.inner_dim = query_dim, ctx_dim, inner
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.to_q = HipLinear(query_dim, inner, bias=bias)
+        self.to_k = HipLinear(ctx_dim, inner, bias=bias)
+        self.to_v = HipLinear(ctx_dim, inner, bias=bias)
+        self.to_out = nn.ModuleList([HipLinear(inner, query_dim, bias=True), nn.Identity()])
+        self.processor = processor if processor is not None else AttnProcessor2_0()
+        self.qkv = self.kv = None
+
+    def set_processor(self, processor, _remove_lora: bool = False):
+        if isinstance(getattr(self, "processor", None), nn.Module) and not isinstance(processor, nn.Module):
+            self._modules.pop("processor", None)
+        self.processor = processor
+
+    def get_processor(self, return_deprecated_lora: bool = False):
+        return self.processor
+
+    def pack(self, arena: WeightArena, dtype):
+        if self.is_cross:
+            self.to_q.pack(arena, dtype)
+            self.kv = pack_concat_rows(arena, dtype, [self.to_k, self.to_v])
+        else:
+            self.qkv = pack_concat_rows(arena, dtype, [self.to_q, self.to_k, self.to_v])
+        self.to_out[0].pack(arena, dtype)
+        if hasattr(self.processor, "pack"):
+            self.processor.pack(arena, dtype)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, **kw)

@@ -1,0 +1,211 @@
+"""ControlNetModel / MultiControlNetModel (SD1.5 configuration) on the HIP kernels.
+
+The reference owns no ControlNet arithmetic: it instantiates diffusers==0.23.0's classes
+(modules/controlresiduals_pipeline.py:18-19,32-38) and calls MultiControlNetModel.forward (:294-302).
+This file keeps that module API -- class names, `nets`, checkpoint keys (conv_in, time_embedding,
+controlnet_cond_embedding.{conv_in,blocks.0-5,conv_out}, down_blocks.*, mid_block.*,
+controlnet_down_blocks.0-11, controlnet_mid_block; cf. the reference's own converter
+animatediff/utils/convert_from_ckpt.py:514-554), forward arguments, `set_attn_processor` -- over the
+same NHWC kernels as the UNet.  Fusions:
+  * the hint embedding (8 convs at up to 512x512) does not depend on the timestep: it is computed
+    once per window and reused by every denoising step (the reference recomputes it each step);
+  * zero-conv epilogue applies conditioning_scale (and the guess-mode logspace factor) and
+    accumulates across nets: MultiControlNet's sum never exists as a separate pass;
+  * conv_in's epilogue adds the hint embedding.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from .context import ExecCtx
+from .layers import HipConv1x1, HipConv3x3
+from .unet import FrozenConfig, HipModelMixin, TimestepEmbedding, Timesteps
+from .unet_blocks import UNetMidBlock3DCrossAttn, get_down_block
+
+
+class ControlNetConditioningEmbedding(nn.Module):
+    def __init__(self, conditioning_embedding_channels: int, conditioning_channels: int = 3,
+                 block_out_channels: Tuple[int, ...] = (16, 32, 96, 256)):
+        super().__init__()
+        self.conv_in = HipConv3x3(conditioning_channels, block_out_channels[0])
+        blocks = []
+        for i in range(len(block_out_channels) - 1):
+            blocks.append(HipConv3x3(block_out_channels[i], block_out_channels[i]))
+            blocks.append(HipConv3x3(block_out_channels[i], block_out_channels[i + 1], stride=2))
+        self.blocks = nn.ModuleList(blocks)
+        self.conv_out = HipConv3x3(block_out_channels[-1], conditioning_embedding_channels)
+        nn.init.zeros_(self.conv_out.weight)  # zero_module in diffusers; checkpoints overwrite it
+
+    def pack(self, arena, dtype):
+        self.conv_in.pack(arena, dtype)
+        for b in self.blocks:
+            b.pack(arena, dtype)
+        self.conv_out.pack(arena, dtype)
+
+    def forward(self, cond_nhwc: torch.Tensor) -> torch.Tensor:
+        e = self.conv_in.run(cond_nhwc, act=K.ACT_SILU)
+        for b in self.blocks:
+            e = b.run(e, act=K.ACT_SILU)
+        return self.conv_out.run(e)
+
+
+class ControlNetModel(HipModelMixin, nn.Module):
+    def __init__(self, in_channels: int = 4, conditioning_channels: int = 3, flip_sin_to_cos: bool = True, freq_shift: int = 0,
+                 down_block_types: Tuple[str, ...] = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+                 only_cross_attention: bool = False, block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280),
+                 layers_per_block: int = 2, downsample_padding: int = 1, mid_block_scale_factor: float = 1, act_fn: str = "silu",
+                 norm_num_groups: int = 32, norm_eps: float = 1e-5, cross_attention_dim: int = 768,
+                 attention_head_dim: Union[int, Tuple[int, ...]] = 8, use_linear_projection: bool = False,
+                 conditioning_embedding_out_channels: Tuple[int, ...] = (16, 32, 96, 256), global_pool_conditions: bool = False,
+                 **unused):
+        super().__init__()
+        self._init_exec()
+        if use_linear_projection or global_pool_conditions:
+            raise NotImplementedError("not part of the SD1.5 ControlNet configuration")
+        cfg = dict(locals())
+        for k in ("self", "unused", "__class__"):
+            cfg.pop(k, None)
+        self.config = FrozenConfig(cfg)
+        time_embed_dim = block_out_channels[0] * 4
+        self.conv_in = HipConv3x3(in_channels, block_out_channels[0])
+        self.time_proj = Timesteps(block_out_channels[0], flip_sin_to_cos, freq_shift)
+        self.time_embedding = TimestepEmbedding(block_out_channels[0], time_embed_dim, act_fn=act_fn)
+        self.controlnet_cond_embedding = ControlNetConditioningEmbedding(block_out_channels[0], conditioning_channels,
+                                                                         conditioning_embedding_out_channels)
+        self.down_blocks = nn.ModuleList([])
+        self.controlnet_down_blocks = nn.ModuleList([HipConv1x1(block_out_channels[0], block_out_channels[0])])
+        if isinstance(attention_head_dim, int):
+            attention_head_dim = (attention_head_dim,) * len(down_block_types)
+        common = dict(temb_channels=time_embed_dim, resnet_eps=norm_eps, resnet_groups=norm_num_groups,
+                      cross_attention_dim=cross_attention_dim, use_inflated_groupnorm=True, use_motion_module=False)
+        output_channel = block_out_channels[0]
+        for i, t in enumerate(down_block_types):
+            input_channel, output_channel = output_channel, block_out_channels[i]
+            is_final = i == len(block_out_channels) - 1
+            self.down_blocks.append(get_down_block(t, num_layers=layers_per_block, in_channels=input_channel,
+                                                   out_channels=output_channel, add_downsample=not is_final,
+                                                   attn_num_head_channels=attention_head_dim[i], **common))
+            for _ in range(layers_per_block + (0 if is_final else 1)):
+                self.controlnet_down_blocks.append(HipConv1x1(output_channel, output_channel))
+        self.controlnet_mid_block = HipConv1x1(block_out_channels[-1], block_out_channels[-1])
+        self.mid_block = UNetMidBlock3DCrossAttn(in_channels=block_out_channels[-1], output_scale_factor=mid_block_scale_factor,
+                                                 attn_num_head_channels=attention_head_dim[-1], **common)
+        for m in list(self.controlnet_down_blocks) + [self.controlnet_mid_block]:
+            nn.init.zeros_(m.weight)  # zero convs; checkpoints overwrite them
+        self._hint_key = None
+        self._hint_emb = None
+
+    @classmethod
+    def from_config(cls, config: dict, **kwargs):
+        merged = {k: v for k, v in dict(config).items() if not k.startswith("_")}
+        merged.update(kwargs)
+        return cls(**merged)
+
+    # ---------------------------------------------------------------------------------------
+    def hint_embedding(self, controlnet_cond: torch.Tensor, device) -> torch.Tensor:
+        """controlnet_cond [B,3,H,W] in [0,1] -> NHWC embedding [B,H/8,W/8,C0]; cached while the same
+        (unmodified) tensor object is passed, i.e. for all denoising steps of a window."""
+        key = self._hint_key
+        if key is not None and key[0] is controlnet_cond and key[1] == controlnet_cond._version and self._hint_emb is not None:
+            return self._hint_emb
+        ce = self.controlnet_cond_embedding
+        nhwc = K.ncfhw_to_nhwc(controlnet_cond.to(device).unsqueeze(2), ce.conv_in.cin_pad, self.act_dtype)
+        self._hint_emb = ce(nhwc)
+        self._hint_key = (controlnet_cond, controlnet_cond._version)
+        return self._hint_emb
+
+    def prepare(self, device=None, dtype=None):
+        self._hint_key = self._hint_emb = None
+        return super().prepare(device, dtype)
+
+    def residual_scales(self, conditioning_scale: float, guess_mode: bool) -> List[float]:
+        n = len(self.controlnet_down_blocks) + 1
+        if guess_mode:
+            return [float(s) * conditioning_scale for s in torch.logspace(-1, 0, n)]
+        return [float(conditioning_scale)] * n
+
+    @torch.no_grad()
+    def forward_nhwc(self, x: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
+                     conditioning_scale: float = 1.0, guess_mode: bool = False,
+                     accumulate: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None):
+        """x: [B,h,w,cin_pad] activation dtype. Returns (12 NHWC residuals, mid), already scaled and --
+        if `accumulate` holds the running sums of previous nets -- added to them."""
+        device = x.device
+        self._ensure_ready(device)
+        images = x.shape[0]
+        ehs, cache = self._prompt(encoder_hidden_states, device)
+        nb = ehs.shape[0]
+        temb = self._time_embedding(timestep, 1, device)
+        ctx = ExecCtx(b=images, f=1, dtype=self.act_dtype, temb=temb, emb_groups=1, ehs=ehs, frames_per_kv=1, kv_mod=nb,
+                      gn_frames_per_stat=1, cache=cache)
+        hint = self.hint_embedding(controlnet_cond, device)
+        if hint.shape[0] != images:
+            raise ValueError(f"controlnet_cond batch {hint.shape[0]} != sample batch {images}")
+        x = self.conv_in.run(x, residual=hint)
+        outs = [x]
+        for blk in self.down_blocks:
+            x, o = blk(x, ctx)
+            outs += o
+        x = self.mid_block(x, ctx)
+        scales = self.residual_scales(conditioning_scale, guess_mode)
+        down = []
+        for i, (zc, o) in enumerate(zip(self.controlnet_down_blocks, outs)):
+            B_, h, w, c = o.shape
+            prev = None if accumulate is None else accumulate[0][i].view(B_ * h * w, c)
+            down.append(zc.run(o.view(B_ * h * w, c), alpha=scales[i], residual=prev).view(B_, h, w, c))
+        B_, h, w, c = x.shape
+        prev = None if accumulate is None else accumulate[1].view(B_ * h * w, c)
+        mid = self.controlnet_mid_block.run(x.view(B_ * h * w, c), alpha=scales[-1], residual=prev).view(B_, h, w, c)
+        return down, mid
+
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
+                conditioning_scale: float = 1.0, class_labels=None, timestep_cond=None, attention_mask=None,
+                cross_attention_kwargs=None, guess_mode: bool = False, return_dict: bool = False):
+        """diffusers-style entry: sample [B,4,h,w] -> (tuple of 12 [B,C,h,w] views, [B,1280,h/8,w/8])."""
+        if not sample.is_cuda:
+            raise RuntimeError("ControlNetModel runs on the HIP device only (no CPU fallback)")
+        self._ensure_ready(sample.device)
+        x = K.ncfhw_to_nhwc(sample.unsqueeze(2), self.conv_in.cin_pad, self.act_dtype)
+        down, mid = self.forward_nhwc(x, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, guess_mode)
+        return tuple(d.permute(0, 3, 1, 2) for d in down), mid.permute(0, 3, 1, 2)
+
+
+class MultiControlNetModel(nn.Module):
+    """diffusers' MultiControlNetModel: runs every net and sums the residuals."""
+
+    def __init__(self, controlnets: Sequence[ControlNetModel]):
+        super().__init__()
+        self.nets = nn.ModuleList(controlnets)
+
+    @property
+    def dtype(self):
+        return self.nets[0].dtype
+
+    def half(self):
+        for n in self.nets:
+            n.half()
+        return self
+
+    def prepare(self, device=None, dtype=None):
+        for n in self.nets:
+            n.prepare(device, dtype)
+        return self
+
+    def forward_nhwc(self, x, timestep, encoder_hidden_states, controlnet_cond: Sequence[torch.Tensor],
+                     conditioning_scale: Sequence[float], guess_mode: bool = False):
+        acc = None
+        for net, cond, scale in zip(self.nets, controlnet_cond, conditioning_scale):
+            acc = net.forward_nhwc(x, timestep, encoder_hidden_states, cond, scale, guess_mode, accumulate=acc)
+        return acc
+
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, class_labels=None,
+                timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, guess_mode=False, return_dict=False):
+        net0 = self.nets[0]
+        net0._ensure_ready(sample.device)
+        x = K.ncfhw_to_nhwc(sample.unsqueeze(2), net0.conv_in.cin_pad, net0.act_dtype)
+        down, mid = self.forward_nhwc(x, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, guess_mode)
+        return tuple(d.permute(0, 3, 1, 2) for d in down), mid.permute(0, 3, 1, 2)

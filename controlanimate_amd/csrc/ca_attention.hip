@@ -23,7 +23,7 @@ struct AttnKParams {
   int64_t q_outer, q_inner, q_row;
   int64_t o_outer, o_inner, o_row;
   int64_t k_outer, k_inner, k_row;
-  int inner_count, kv_inner_count, kv_div;
+  int inner_count, kv_inner_count, kv_div, kv_mod;
   int batches, heads, head_dim, nq, nk;
   int qblocks;
   float scale_log2;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   const int z = bid / p.heads;
 
   const int zo = z / p.inner_count, zi = z - zo * p.inner_count;
-  const int zk = z / p.kv_div;
+  const int zk = (z / p.kv_div) % p.kv_mod;
   const int zko = zk / p.kv_inner_count, zki = zk - zko * p.kv_inner_count;
   const u16* qp = p.q + zo * p.q_outer + zi * p.q_inner + (int64_t)head * p.head_dim;
   u16* op = p.o + zo * p.o_outer + zi * p.o_inner + (int64_t)head * p.head_dim;
@@ -277,6 +277,7 @@ extern "C" int ca_attention(const ca_attn_args* a, void* stream) {
   p.inner_count = a->inner_count;
   p.kv_inner_count = a->kv_inner_count;
   p.kv_div = a->kv_div;
+  p.kv_mod = a->kv_mod > 0 ? a->kv_mod : a->batches;
   p.batches = a->batches;
   p.heads = a->heads;
   p.head_dim = a->head_dim;

@@ -153,7 +153,7 @@ def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, pos:
 def attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, *, q_off: int, k_off: int,
                   v_off: int, o_off: int, q_strides, o_strides, k_strides, inner_count: int, kv_inner_count: int,
                   kv_div: int, batches: int, heads: int, head_dim: int, nq: int, nk: int, scale: float,
-                  out_scale: float = 1.0, accumulate: bool = False) -> None:
+                  out_scale: float = 1.0, accumulate: bool = False, kv_mod: int = 0) -> None:
     """Direct mapping of ca_attention. *_off are element offsets into the given storage tensors;
     *_strides = (outer, inner, row) in elements."""
     _req_cuda(q, k, v, o)
@@ -163,8 +163,8 @@ def attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Te
                     q_outer=q_strides[0], q_inner=q_strides[1], q_row=q_strides[2],
                     o_outer=o_strides[0], o_inner=o_strides[1], o_row=o_strides[2],
                     k_outer=k_strides[0], k_inner=k_strides[1], k_row=k_strides[2],
-                    inner_count=inner_count, kv_inner_count=kv_inner_count, kv_div=kv_div, batches=batches,
-                    heads=heads, head_dim=head_dim, nq=nq, nk=nk, scale=scale, out_scale=out_scale,
+                    inner_count=inner_count, kv_inner_count=kv_inner_count, kv_div=kv_div,
+                    kv_mod=kv_mod if kv_mod > 0 else batches, batches=batches, heads=heads, head_dim=head_dim, nq=nq, nk=nk, scale=scale, out_scale=out_scale,
                     accumulate=int(accumulate), dtype=dt_code(q.dtype))
     check(lib().ca_attention(C.byref(args), _stream()), "ca_attention")
 
@@ -184,9 +184,10 @@ def attention_spatial(qkv: torch.Tensor, images: int, tokens: int, heads: int) -
 
 def attention_cross(q: torch.Tensor, kv: torch.Tensor, images: int, tokens: int, heads: int, kv_tokens: int,
                     kv_rows_per_batch: int, frames_per_kv: int, *, out: Optional[torch.Tensor] = None,
-                    out_scale: float = 1.0, accumulate: bool = False, kv_row_offset: int = 0) -> torch.Tensor:
+                    out_scale: float = 1.0, accumulate: bool = False, kv_row_offset: int = 0,
+                    kv_mod: int = 0) -> torch.Tensor:
     """Cross-attention. q: [images*tokens, C]; kv: [kv_batches*kv_rows_per_batch, 2C] (k | v).
-    Image z uses kv batch z // frames_per_kv, rows [kv_row_offset, kv_row_offset + kv_tokens)."""
+    Image z uses kv batch (z // frames_per_kv) % kv_mod, rows [kv_row_offset, kv_row_offset + kv_tokens)."""
     c = q.shape[1]
     d = c // heads
     if out is None:
@@ -196,7 +197,7 @@ def attention_cross(q: torch.Tensor, kv: torch.Tensor, images: int, tokens: int,
                   q_strides=(tokens * q.stride(0), 0, q.stride(0)), o_strides=(tokens * out.stride(0), 0, out.stride(0)),
                   k_strides=(kv_rows_per_batch * ldk, 0, ldk), inner_count=1, kv_inner_count=1,
                   kv_div=frames_per_kv, batches=images, heads=heads, head_dim=d, nq=tokens, nk=kv_tokens,
-                  scale=d ** -0.5, out_scale=out_scale, accumulate=accumulate)
+                  scale=d ** -0.5, out_scale=out_scale, accumulate=accumulate, kv_mod=kv_mod)
     return out
 
 

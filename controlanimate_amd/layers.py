@@ -1,0 +1,195 @@
+"""Leaf layers of the HIP execution path: parameter containers with the reference's checkpoint
+names + packed, kernel-friendly device copies of their weights.
+
+Master parameters (nn.Parameter, any float dtype, any device) exist for state-dict
+compatibility with the reference's checkpoints.  `WeightArena` gathers every packed
+tensor of a model into ONE contiguous device buffer (so multi-GPU start-up is a single RCCL
+broadcast) laid out as the kernels want it:
+  * Linear / 1x1 conv:  [N, K] row-major in the activation dtype (both MFMA operands K-contiguous)
+  * 3x3 conv:           [Cout, kh, kw, Cin]  (Cin padded to a multiple of 8 with zeros)
+  * fused projections:  q|k|v (self-attention) and k|v (cross-attention) concatenated along N
+  * GEGLU:              rows interleaved (h0, g0, h1, g1, ...) so the gate sits next to its value
+  * biases, norm affine parameters, positional tables: fp32
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import kernels as K
+
+ALIGN = 256  # bytes
+
+
+class Packed:
+    """Handle to one packed tensor inside the arena (valid after WeightArena.finalize)."""
+
+    __slots__ = ("shape", "dtype", "fill", "offset", "t")
+
+    def __init__(self, shape, dtype, fill):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = dtype
+        self.fill = fill
+        self.offset = -1
+        self.t: Optional[torch.Tensor] = None
+
+    @property
+    def nbytes(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n * torch.empty((), dtype=self.dtype).element_size()
+
+
+class WeightArena:
+    def __init__(self):
+        self.items: List[Packed] = []
+        self.buffer: Optional[torch.Tensor] = None
+
+    def add(self, shape, dtype, fill: Callable[[], torch.Tensor]) -> Packed:
+        p = Packed(shape, dtype, fill)
+        self.items.append(p)
+        return p
+
+    def finalize(self, device) -> torch.Tensor:
+        off = 0
+        for p in self.items:
+            p.offset = off
+            off += (p.nbytes + ALIGN - 1) // ALIGN * ALIGN
+        self.buffer = torch.zeros(max(off, ALIGN), dtype=torch.uint8, device=device)
+        for p in self.items:
+            view = self.buffer[p.offset:p.offset + p.nbytes].view(p.dtype).view(p.shape)
+            src = p.fill()
+            assert tuple(src.shape) == p.shape, (tuple(src.shape), p.shape)
+            view.copy_(src.to(device=device, dtype=p.dtype, non_blocking=False))
+            p.t = view
+            p.fill = None
+        return self.buffer
+
+    @property
+    def nbytes(self) -> int:
+        return 0 if self.buffer is None else self.buffer.numel()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().float()
+
+
+class HipLinear(nn.Module):
+    """nn.Linear-compatible parameters (weight [N,K], bias [N]); executes via ca_gemm."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        nn.init.normal_(self.weight, std=in_features ** -0.5)
+        if bias:
+            nn.init.zeros_(self.bias)
+        self.w: Optional[Packed] = None
+        self.b: Optional[Packed] = None
+
+    def pack(self, arena: WeightArena, dtype):
+        self.w = arena.add((self.out_features, self.in_features), dtype, lambda: _f32(self.weight))
+        self.b = arena.add((self.out_features,), torch.float32, lambda: _f32(self.bias)) if self.bias is not None else None
+
+    def run(self, a: torch.Tensor, **kw) -> torch.Tensor:
+        return K.gemm(a, self.w.t, bias=None if self.b is None else self.b.t, **kw)
+
+
+class HipConv1x1(nn.Module):
+    """Conv2d 1x1 parameters (weight [Cout,Cin,1,1]); a plain row-major GEMM in NHWC."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.normal_(self.weight, std=in_channels ** -0.5)
+        self.w = self.b = None
+
+    def pack(self, arena: WeightArena, dtype):
+        self.w = arena.add((self.out_channels, self.in_channels), dtype, lambda: _f32(self.weight).reshape(self.out_channels, self.in_channels))
+        self.b = arena.add((self.out_channels,), torch.float32, lambda: _f32(self.bias))
+
+    def run(self, a: torch.Tensor, **kw) -> torch.Tensor:
+        return K.gemm(a, self.w.t, bias=self.b.t, **kw)
+
+
+class HipConv3x3(nn.Module):
+    """Conv2d 3x3 pad 1 parameters (weight [Cout,Cin,3,3]); NHWC implicit GEMM via ca_conv3x3."""
+
+    def __init__(self, in_channels: int, out_channels: int, stride: int = 1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.cin_pad = (in_channels + 7) // 8 * 8
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.normal_(self.weight, std=(9 * in_channels) ** -0.5)
+        self.w = self.b = None
+
+    def _packed_weight(self) -> torch.Tensor:
+        w = _f32(self.weight).permute(0, 2, 3, 1)  # [Cout, kh, kw, Cin]
+        if self.cin_pad != self.in_channels:
+            w = torch.nn.functional.pad(w, (0, self.cin_pad - self.in_channels))
+        return w.contiguous()
+
+    def pack(self, arena: WeightArena, dtype):
+        self.w = arena.add((self.out_channels, 3, 3, self.cin_pad), dtype, self._packed_weight)
+        self.b = arena.add((self.out_channels,), torch.float32, lambda: _f32(self.bias))
+
+    def run(self, x: torch.Tensor, **kw) -> torch.Tensor:
+        return K.conv3x3(x, self.w.t, bias=self.b.t, stride=self.stride, **kw)
+
+
+class HipGroupNorm(nn.Module):
+    def __init__(self, num_groups: int, num_channels: int, eps: float = 1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+        self.g = self.b = None
+
+    def pack(self, arena: WeightArena, dtype):
+        self.g = arena.add((self.num_channels,), torch.float32, lambda: _f32(self.weight))
+        self.b = arena.add((self.num_channels,), torch.float32, lambda: _f32(self.bias))
+
+    def run(self, x: torch.Tensor, *, x2: Optional[torch.Tensor] = None, frames_per_stat: int = 1, act: int = K.ACT_NONE):
+        return K.group_norm(x, self.g.t, self.b.t, x2=x2, groups=self.num_groups, frames_per_stat=frames_per_stat,
+                            eps=self.eps, act=act)
+
+
+class HipLayerNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.g = self.b = None
+
+    def pack(self, arena: WeightArena, dtype):
+        self.g = arena.add((self.dim,), torch.float32, lambda: _f32(self.weight))
+        self.b = arena.add((self.dim,), torch.float32, lambda: _f32(self.bias))
+
+    def run(self, x: torch.Tensor, *, pos: Optional[torch.Tensor] = None, rows_per_frame: int = 1, frames: int = 1):
+        return K.layer_norm(x, self.g.t, self.b.t, pos=pos, rows_per_frame=rows_per_frame, frames=frames, eps=self.eps)
+
+
+def pack_concat_rows(arena: WeightArena, dtype, mods: Sequence[nn.Module]) -> Packed:
+    """One [sum N_i, K] matrix from several Linear weights (fused q|k|v or k|v projections)."""
+    n = sum(m.weight.shape[0] for m in mods)
+    k = mods[0].weight.shape[1]
+    return arena.add((n, k), dtype, lambda: torch.cat([_f32(m.weight).reshape(m.weight.shape[0], -1) for m in mods], 0))
+
+
+def pack_concat_bias(arena: WeightArena, mods: Sequence[nn.Module]) -> Packed:
+    n = sum(m.weight.shape[0] for m in mods)
+    return arena.add((n,), torch.float32, lambda: torch.cat([_f32(m.bias) for m in mods], 0))
+
+
+def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
+    """[2D, ...] (value rows then gate rows) -> rows (v0, g0, v1, g1, ...)."""
+    d = w.shape[0] // 2
+    return torch.stack([w[:d], w[d:]], dim=1).reshape(w.shape)

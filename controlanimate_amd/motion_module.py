@@ -1,0 +1,151 @@
+"""AnimateDiff motion module (temporal transformer) on HIP kernels.
+
+Mirrors the reference's animatediff/models/motion_module.py in names and checkpoint keys
+(VanillaTemporalModule :50-84, TemporalTransformer3DModel :87-160, TemporalTransformerBlock
+:163-224, PositionalEncoding :227-245, VersatileAttention :248-344).  Differences in execution:
+  * no '(b f) d c -> (b d) f c' transposes: the attention kernel walks the frame axis with a
+    row stride of tokens*C inside the (b f n) row order (SURVEY 2.1 "Temporal self-attention");
+  * `x + pe[:, :f]` is fused into the preceding LayerNorm kernel (rows know their frame);
+  * q|k|v is ONE GEMM and is computed once (the reference computes q, k, v, discards them and lets
+    the processor recompute, motion_module.py:299-311 -- no effect on outputs, not reproduced);
+  * residual adds live in the GEMM epilogues.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from .attention import FeedForward
+from .attention_processor import Attention
+from .context import ExecCtx
+from .layers import HipGroupNorm, HipLayerNorm, HipLinear, WeightArena, _f32
+
+
+def get_motion_module(in_channels, motion_module_type: str, motion_module_kwargs: dict):
+    if motion_module_type == "Vanilla":
+        return VanillaTemporalModule(in_channels=in_channels, **motion_module_kwargs)
+    raise ValueError(motion_module_type)
+
+
+class PositionalEncoding(nn.Module):
+    def __init__(self, d_model, dropout=0.0, max_len=24):
+        super().__init__()
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(1, max_len, d_model)
+        pe[0, :, 0::2] = torch.sin(position * div_term)
+        pe[0, :, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe)  # in the checkpoint: ...pos_encoder.pe
+        self.max_len = max_len
+        self.table = None
+
+    def pack(self, arena: WeightArena, dtype):
+        self.table = arena.add((self.pe.shape[1], self.pe.shape[2]), torch.float32, lambda: _f32(self.pe)[0])
+
+
+class VersatileAttention(Attention):
+    def __init__(self, attention_mode=None, cross_frame_attention_mode=None, temporal_position_encoding=False,
+                 temporal_position_encoding_max_len=24, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert attention_mode == "Temporal"
+        self.attention_mode = attention_mode
+        self.is_cross_attention = kwargs.get("cross_attention_dim") is not None
+        if self.is_cross_attention:
+            raise NotImplementedError("Temporal_Cross is not used by inference-v{1,2}.yaml")
+        self.pos_encoder = PositionalEncoding(kwargs["query_dim"], max_len=temporal_position_encoding_max_len) \
+            if temporal_position_encoding else None
+
+    def pack(self, arena, dtype):
+        super().pack(arena, dtype)
+        if self.pos_encoder is not None:
+            self.pos_encoder.pack(arena, dtype)
+
+    def pos_table(self, frames: int):
+        if self.pos_encoder is None:
+            return None
+        if frames > self.pos_encoder.max_len:
+            raise ValueError(f"video_length {frames} exceeds temporal_position_encoding_max_len {self.pos_encoder.max_len}")
+        return self.pos_encoder.table.t[:frames]
+
+
+class TemporalTransformerBlock(nn.Module):
+    def __init__(self, dim, num_attention_heads, attention_head_dim, attention_block_types=("Temporal_Self", "Temporal_Self"),
+                 dropout=0.0, cross_attention_dim=768, activation_fn="geglu", attention_bias=False, upcast_attention=False,
+                 cross_frame_attention_mode=None, temporal_position_encoding=False, temporal_position_encoding_max_len=24, **_):
+        super().__init__()
+        self.attention_blocks = nn.ModuleList([
+            VersatileAttention(attention_mode=name.split("_")[0],
+                               cross_attention_dim=cross_attention_dim if name.endswith("_Cross") else None,
+                               query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim, bias=attention_bias,
+                               temporal_position_encoding=temporal_position_encoding,
+                               temporal_position_encoding_max_len=temporal_position_encoding_max_len)
+            for name in attention_block_types])
+        self.norms = nn.ModuleList([HipLayerNorm(dim) for _ in attention_block_types])
+        self.ff = FeedForward(dim, activation_fn=activation_fn)
+        self.ff_norm = HipLayerNorm(dim)
+
+    def pack(self, arena, dtype):
+        for m in list(self.attention_blocks) + list(self.norms) + [self.ff, self.ff_norm]:
+            m.pack(arena, dtype)
+
+    def forward(self, x: torch.Tensor, ctx: ExecCtx, tokens: int) -> torch.Tensor:
+        """x: [(b f n), C] rows."""
+        rows, C = x.shape
+        for attn, norm in zip(self.attention_blocks, self.norms):
+            n = norm.run(x, pos=attn.pos_table(ctx.f), rows_per_frame=tokens, frames=ctx.f)
+            x = attn(n.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens)).view(rows, C)
+        return self.ff.run(self.ff_norm.run(x), residual=x)
+
+
+class TemporalTransformer3DModel(nn.Module):
+    def __init__(self, in_channels, num_attention_heads, attention_head_dim, num_layers, norm_num_groups=32, **kw):
+        super().__init__()
+        inner = num_attention_heads * attention_head_dim
+        self.norm = HipGroupNorm(norm_num_groups, in_channels, eps=1e-6)
+        self.proj_in = HipLinear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([
+            TemporalTransformerBlock(dim=inner, num_attention_heads=num_attention_heads,
+                                     attention_head_dim=attention_head_dim, **kw) for _ in range(num_layers)])
+        self.proj_out = HipLinear(inner, in_channels)
+
+    def pack(self, arena, dtype):
+        self.norm.pack(arena, dtype)
+        self.proj_in.pack(arena, dtype)
+        for b in self.transformer_blocks:
+            b.pack(arena, dtype)
+        self.proj_out.pack(arena, dtype)
+
+    def forward(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
+        images, h, w, c = x.shape
+        rows = images * h * w
+        y = self.norm.run(x)  # per image ('(b f) c h w', motion_module.py:139-144)
+        y = self.proj_in.run(y.view(rows, c))
+        for blk in self.transformer_blocks:
+            y = blk(y, ctx, h * w)
+        return self.proj_out.run(y, residual=x.view(rows, c)).view(images, h, w, c)
+
+
+class VanillaTemporalModule(nn.Module):
+    def __init__(self, in_channels, num_attention_heads=8, num_transformer_block=2,
+                 attention_block_types=("Temporal_Self", "Temporal_Self"), cross_frame_attention_mode=None,
+                 temporal_position_encoding=False, temporal_position_encoding_max_len=24, temporal_attention_dim_div=1,
+                 zero_initialize=True):
+        super().__init__()
+        self.temporal_transformer = TemporalTransformer3DModel(
+            in_channels=in_channels, num_attention_heads=num_attention_heads,
+            attention_head_dim=in_channels // num_attention_heads // temporal_attention_dim_div,
+            num_layers=num_transformer_block, attention_block_types=attention_block_types,
+            cross_frame_attention_mode=cross_frame_attention_mode, temporal_position_encoding=temporal_position_encoding,
+            temporal_position_encoding_max_len=temporal_position_encoding_max_len)
+        if zero_initialize:  # motion_module.py:76-77; real checkpoints overwrite it
+            nn.init.zeros_(self.temporal_transformer.proj_out.weight)
+            nn.init.zeros_(self.temporal_transformer.proj_out.bias)
+
+    def pack(self, arena, dtype):
+        self.temporal_transformer.pack(arena, dtype)
+
+    def forward(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
+        return self.temporal_transformer(x, ctx)

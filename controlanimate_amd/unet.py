@@ -1,0 +1,436 @@
+"""UNet3DConditionModel (AnimateDiff-inflated SD1.5 UNet) executing on hand-written HIP kernels.
+
+API parity with the reference's animatediff/models/unet.py (ctor :54-319, attn_processors /
+set_attn_processor :324-382, forward :458-621, from_pretrained_2d :623-669): same constructor
+arguments, same sub-module names (=> same state-dict keys as SD1.5 + motion-module checkpoints),
+same forward signature and output type.  What is different is everything underneath:
+
+  * activations live as channels-last [b*f, h, w, c] in bf16/fp16 (one layout end to end, no
+    einops rearranges, no transposes around temporal attention);
+  * weights are packed once (`prepare()`) into a single device arena in kernel layout;
+  * every op of the forward is a call into libcontrolanimate_hip.so (C ABI in
+    include/controlanimate_hip.h); there is no eager / CPU fallback;
+  * the 22 time_emb_proj linears run as ONE GEMM per step; prompt K/V are cached across steps;
+    the duplicate time-embedding evaluation (unet.py:532) is not reproduced (no output effect).
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from .context import ExecCtx
+from .layers import HipGroupNorm, HipLinear, WeightArena, pack_concat_bias, pack_concat_rows
+from .resnet import InflatedConv3d, InflatedGroupNorm, ResnetBlock3D
+from .unet_blocks import UNetMidBlock3DCrossAttn, get_down_block, get_up_block
+
+
+@dataclass
+class UNet3DConditionOutput:
+    sample: torch.Tensor
+
+
+class FrozenConfig(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class Timesteps(nn.Module):
+    def __init__(self, num_channels: int, flip_sin_to_cos: bool = True, downscale_freq_shift: float = 0):
+        super().__init__()
+        if not flip_sin_to_cos or downscale_freq_shift != 0:
+            raise NotImplementedError("SD1.5 uses flip_sin_to_cos=True, freq_shift=0")
+        self.num_channels = num_channels
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels: int, time_embed_dim: int, act_fn: str = "silu", post_act_fn=None, cond_proj_dim=None):
+        super().__init__()
+        self.linear_1 = HipLinear(in_channels, time_embed_dim)
+        self.cond_proj = HipLinear(cond_proj_dim, in_channels, bias=False) if cond_proj_dim is not None else None
+        self.linear_2 = HipLinear(time_embed_dim, time_embed_dim)
+
+    def pack(self, arena, dtype):
+        self.linear_1.pack(arena, dtype)
+        self.linear_2.pack(arena, dtype)
+        if self.cond_proj is not None:
+            self.cond_proj.pack(arena, dtype)
+
+
+class HipModelMixin:
+    """prepare()/packing, dtype switches and processor plumbing shared by UNet3D and ControlNet."""
+
+    def _init_exec(self):
+        self.arena: Optional[WeightArena] = None
+        # fp16 is the reference's own inference dtype (.half(), modules/controlanimate_pipeline.py:108-110)
+        # and meets the 1e-2 eps tolerance with margin (measured 2.5e-3); bf16 is selectable
+        # (prepare(dtype=torch.bfloat16)) for range safety but measures 1.8e-2 through the ~150 residual adds.
+        self.act_dtype = torch.float16
+        self._temb_w = self._temb_b = None
+        self._cache: dict = {}
+        self._cache_key = None
+
+    # ---- weights ---------------------------------------------------------------------------
+    def all_resnets(self):
+        return [m for m in self.modules() if isinstance(m, ResnetBlock3D)]
+
+    def prepare(self, device=None, dtype: Optional[torch.dtype] = None) -> "HipModelMixin":
+        """Packs all weights into one device arena in kernel layout (call after loading weights,
+        and again after changing weights or installing processors with parameters)."""
+        if dtype is not None:
+            self.act_dtype = dtype
+        if device is None:
+            device = next(self.parameters()).device
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("prepare() needs a HIP device: the execution path has no CPU fallback")
+        K.lib()  # fail loudly if the extension is missing
+        arena = WeightArena()
+        for child in self.children():
+            self._pack_tree(child, arena)
+        resnets = self.all_resnets()
+        off = 0
+        for r in resnets:
+            r.temb_slice = (off, off + r.out_channels)
+            off += r.out_channels
+        self._temb_w = pack_concat_rows(arena, self.act_dtype, [r.time_emb_proj for r in resnets])
+        self._temb_b = pack_concat_bias(arena, [r.time_emb_proj for r in resnets])
+        arena.finalize(device)
+        self.arena = arena
+        self._cache, self._cache_key = {}, None
+        return self
+
+    def _pack_tree(self, m: nn.Module, arena: WeightArena):
+        if hasattr(m, "pack"):
+            m.pack(arena, self.act_dtype)
+            return
+        for c in m.children():
+            self._pack_tree(c, arena)
+
+    def release_master_weights(self):
+        """Frees the fp32 master parameters (keeps only the packed arena). state_dict() is empty-valued after this."""
+        for p in self.parameters():
+            p.data = torch.empty(0, dtype=p.dtype, device=p.device)
+
+    def half(self):
+        self.act_dtype = torch.float16
+        self.arena = None
+        return self
+
+    def bfloat16(self):
+        self.act_dtype = torch.bfloat16
+        self.arena = None
+        return self
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.act_dtype
+
+    @property
+    def device(self) -> torch.device:
+        if self.arena is not None and self.arena.buffer is not None:
+            return self.arena.buffer.device
+        return next(self.parameters()).device
+
+    def _ensure_ready(self, device):
+        if self.arena is None or self.arena.buffer is None or self.arena.buffer.device != device:
+            self.prepare(device)
+
+    # ---- processors (reference unet.py:324-382) ----------------------------------------------
+    @property
+    def attn_processors(self) -> Dict[str, Any]:
+        procs: Dict[str, Any] = {}
+
+        def rec(name, module):
+            if hasattr(module, "get_processor"):
+                procs[f"{name}.processor"] = module.get_processor(return_deprecated_lora=True)
+            for sub, child in module.named_children():
+                rec(f"{name}.{sub}", child)
+
+        for name, module in self.named_children():
+            rec(name, module)
+        return procs
+
+    def set_attn_processor(self, processor, _remove_lora=False):
+        count = len(self.attn_processors)
+        if isinstance(processor, dict) and len(processor) != count:
+            raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+                             f" number of attention layers: {count}. Please make sure to pass {count} processor classes.")
+        processor = dict(processor) if isinstance(processor, dict) else processor
+
+        def rec(name, module):
+            if hasattr(module, "set_processor"):
+                module.set_processor(processor if not isinstance(processor, dict) else processor.pop(f"{name}.processor"),
+                                     _remove_lora=_remove_lora)
+            for sub, child in module.named_children():
+                rec(f"{name}.{sub}", child)
+
+        for name, module in self.named_children():
+            rec(name, module)
+        self.arena = None  # processors may carry weights (IP-Adapter): re-pack lazily
+
+    # ---- shared pieces of forward -------------------------------------------------------------
+    def _time_embedding(self, timestep, groups: int, device, timestep_cond=None) -> torch.Tensor:
+        """-> silu(emb) projected through every resnet's time_emb_proj: fp32 [groups, sum C_out]."""
+        dim = self.time_proj.num_channels
+        if torch.is_tensor(timestep) and timestep.numel() > 1:
+            if timestep.numel() != groups:
+                raise ValueError("timestep tensor must be a scalar or one value per batch element")
+            t = timestep.to(device=device, dtype=torch.float32).contiguous()
+            t_emb = K.timestep_embedding(t, groups, dim, self.act_dtype, device)
+        else:
+            tv = float(timestep.item()) if torch.is_tensor(timestep) else float(timestep)
+            t_emb = K.timestep_embedding(tv, groups, dim, self.act_dtype, device)
+        te = self.time_embedding
+        if timestep_cond is not None:
+            if te.cond_proj is None:
+                raise ValueError("timestep_cond given but the model has no time_cond_proj_dim")
+            cond = timestep_cond.to(device=device, dtype=self.act_dtype)
+            if cond.shape[0] != groups:
+                cond = cond.expand(groups, -1)
+            t_emb = K.gemm(cond.contiguous(), te.cond_proj.w.t, residual=t_emb)
+        h = te.linear_1.run(t_emb, act=K.ACT_SILU)
+        emb = te.linear_2.run(h, act=K.ACT_SILU)  # silu(emb): every consumer applies nonlinearity first (resnet.py:196)
+        return K.gemm(emb, self._temb_w.t, bias=self._temb_b.t, out_f32=True)
+
+    def _prompt(self, encoder_hidden_states: torch.Tensor, device) -> Tuple[torch.Tensor, dict]:
+        """Prompt embeddings in the activation dtype + the K/V cache that belongs to them. The cache
+        survives across calls only while the caller passes the very same (unmodified) tensor."""
+        key = self._cache_key
+        if key is not None and key[0] is encoder_hidden_states and key[1] == encoder_hidden_states._version:
+            return self._cache["ehs"], self._cache
+        ehs = encoder_hidden_states.to(device=device, dtype=self.act_dtype).contiguous()
+        self._cache = {"ehs": ehs}
+        self._cache_key = (encoder_hidden_states, encoder_hidden_states._version)
+        return ehs, self._cache
+
+
+class UNet3DConditionModel(HipModelMixin, nn.Module):
+    _supports_gradient_checkpointing = False
+
+    def __init__(
+        self,
+        sample_size: Optional[int] = None,
+        in_channels: int = 4,
+        out_channels: int = 4,
+        center_input_sample: bool = False,
+        flip_sin_to_cos: bool = True,
+        freq_shift: int = 0,
+        down_block_types: Tuple[str, ...] = ("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"),
+        mid_block_type: str = "UNetMidBlock3DCrossAttn",
+        up_block_types: Tuple[str, ...] = ("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"),
+        only_cross_attention: Union[bool, Tuple[bool, ...]] = False,
+        block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280),
+        layers_per_block: int = 2,
+        downsample_padding: int = 1,
+        mid_block_scale_factor: float = 1,
+        act_fn: str = "silu",
+        norm_num_groups: int = 32,
+        norm_eps: float = 1e-5,
+        cross_attention_dim: int = 1280,
+        attention_head_dim: Union[int, Tuple[int, ...]] = 8,
+        dual_cross_attention: bool = False,
+        use_linear_projection: bool = False,
+        class_embed_type: Optional[str] = None,
+        num_class_embeds: Optional[int] = None,
+        upcast_attention: bool = False,
+        resnet_time_scale_shift: str = "default",
+        use_inflated_groupnorm: bool = False,
+        time_cond_proj_dim: Optional[int] = None,
+        # animatediff additions
+        use_motion_module: bool = False,
+        motion_module_resolutions: Tuple[int, ...] = (1, 2, 4, 8),
+        motion_module_mid_block: bool = False,
+        motion_module_decoder_only: bool = False,
+        motion_module_type: Optional[str] = None,
+        motion_module_kwargs: Optional[dict] = None,
+        unet_use_cross_frame_attention: Optional[bool] = None,
+        unet_use_temporal_attention: Optional[bool] = None,
+        **unused,
+    ):
+        super().__init__()
+        self._init_exec()
+        if class_embed_type is not None or num_class_embeds is not None or dual_cross_attention or use_linear_projection:
+            raise NotImplementedError("not part of the SD1.5 configuration the reference runs")
+        if act_fn not in ("silu", "swish") or resnet_time_scale_shift != "default" or center_input_sample:
+            raise NotImplementedError("SD1.5 uses silu / default time-embedding norm")
+        cfg = dict(locals())
+        for k in ("self", "unused", "__class__"):
+            cfg.pop(k, None)
+        cfg.update(unused)
+        self.config = FrozenConfig(cfg)
+        self.sample_size = sample_size
+        self.in_channels = in_channels
+        motion_module_kwargs = dict(motion_module_kwargs or {})
+        time_embed_dim = block_out_channels[0] * 4
+
+        self.conv_in = InflatedConv3d(in_channels, block_out_channels[0])
+        self.time_proj = Timesteps(block_out_channels[0], flip_sin_to_cos, freq_shift)
+        self.time_embedding = TimestepEmbedding(block_out_channels[0], time_embed_dim, act_fn=act_fn, cond_proj_dim=time_cond_proj_dim)
+
+        # registration order down_blocks, up_blocks, mid_block matches the reference (mid_block is
+        # first assigned None there, unet.py:166-168), which fixes the attn_processors enumeration
+        # that the IP-Adapter loader indexes into (modules/ip_adapter.py:150-180).
+        self.down_blocks = nn.ModuleList([])
+        self.up_blocks = nn.ModuleList([])
+        if isinstance(attention_head_dim, int):
+            attention_head_dim = (attention_head_dim,) * len(down_block_types)
+        common = dict(temb_channels=time_embed_dim, resnet_eps=norm_eps, resnet_groups=norm_num_groups,
+                      cross_attention_dim=cross_attention_dim, use_inflated_groupnorm=use_inflated_groupnorm,
+                      motion_module_type=motion_module_type, motion_module_kwargs=motion_module_kwargs,
+                      unet_use_cross_frame_attention=bool(unet_use_cross_frame_attention),
+                      unet_use_temporal_attention=bool(unet_use_temporal_attention))
+        output_channel = block_out_channels[0]
+        for i, t in enumerate(down_block_types):
+            res = 2 ** i
+            input_channel, output_channel = output_channel, block_out_channels[i]
+            self.down_blocks.append(get_down_block(
+                t, num_layers=layers_per_block, in_channels=input_channel, out_channels=output_channel,
+                add_downsample=i != len(block_out_channels) - 1, attn_num_head_channels=attention_head_dim[i],
+                use_motion_module=use_motion_module and (res in motion_module_resolutions) and not motion_module_decoder_only,
+                **common))
+        if mid_block_type != "UNetMidBlock3DCrossAttn":
+            raise ValueError(f"unknown mid_block_type : {mid_block_type}")
+        mid = UNetMidBlock3DCrossAttn(in_channels=block_out_channels[-1], output_scale_factor=mid_block_scale_factor,
+                                      attn_num_head_channels=attention_head_dim[-1],
+                                      use_motion_module=use_motion_module and motion_module_mid_block, **common)
+        self.num_upsamplers = 0
+        rev = list(reversed(block_out_channels))
+        rev_heads = list(reversed(attention_head_dim))
+        output_channel = rev[0]
+        for i, t in enumerate(up_block_types):
+            res = 2 ** (3 - i)
+            is_final = i == len(block_out_channels) - 1
+            prev_output_channel, output_channel = output_channel, rev[i]
+            input_channel = rev[min(i + 1, len(block_out_channels) - 1)]
+            if not is_final:
+                self.num_upsamplers += 1
+            self.up_blocks.append(get_up_block(
+                t, num_layers=layers_per_block + 1, in_channels=input_channel, out_channels=output_channel,
+                prev_output_channel=prev_output_channel, add_upsample=not is_final, attn_num_head_channels=rev_heads[i],
+                use_motion_module=use_motion_module and (res in motion_module_resolutions), **common))
+        self.mid_block = mid
+        self.conv_norm_out = InflatedGroupNorm(norm_num_groups, block_out_channels[0], norm_eps)
+        self.conv_act = nn.SiLU()
+        self.conv_out = InflatedConv3d(block_out_channels[0], out_channels)
+
+    # ---------------------------------------------------------------------------------------
+    def _to_nhwc(self, t: torch.Tensor, device, cpad: Optional[int] = None) -> torch.Tensor:
+        """[b,c,f,h,w] (any float dtype / strides) -> [b*f,h,w,c] activation dtype.  Zero-copy when the
+        tensor already is a channels-last view in the activation dtype (ControlNet residuals from
+        MultiControlNetResidualsPipeline are handed over that way)."""
+        b, c, f, h, w = t.shape
+        cpad = cpad or c
+        want = (f * h * w * c, 1, h * w * c, w * c, c)
+        if (t.is_cuda and t.dtype == self.act_dtype and cpad == c
+                and all(n == 1 or s == e for n, s, e in zip(t.shape, t.stride(), want))):
+            return t.permute(0, 2, 3, 4, 1).reshape(b * f, h, w, c)
+        return K.ncfhw_to_nhwc(t.to(device), cpad, self.act_dtype)
+
+    @torch.no_grad()
+    def forward_nhwc(self, x: torch.Tensor, b: int, f: int, timestep, encoder_hidden_states: torch.Tensor,
+                     down_residuals=None, mid_residual=None, timestep_cond=None) -> torch.Tensor:
+        """The whole forward on channels-last tensors (what the denoising loop calls directly).
+        x: [b*f, h, w, cin_pad] activation dtype; residuals: NHWC with b*f or f images (broadcast over b);
+        returns eps [b*f, h, w, out_channels] fp32."""
+        device = x.device
+        self._ensure_ready(device)
+        _, h, w, _ = x.shape
+        if any(s % (2 ** self.num_upsamplers) for s in (h, w)):
+            raise NotImplementedError("latent height/width must be multiples of 8 (vid2vid.py floors frames to /64)")
+        ehs, cache = self._prompt(encoder_hidden_states, device)
+        if ehs.shape[0] != b:
+            raise ValueError(f"encoder_hidden_states batch {ehs.shape[0]} != sample batch {b}")
+        temb = self._time_embedding(timestep, b, device, timestep_cond)
+        ctx = ExecCtx(b=b, f=f, dtype=self.act_dtype, temb=temb, emb_groups=b, ehs=ehs, frames_per_kv=f,
+                      gn_frames_per_stat=1 if self.config.use_inflated_groupnorm else f, cache=cache)
+        x = self.conv_in.run(x)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, ctx)
+            skips += outs
+        if down_residuals is not None:
+            if len(down_residuals) != len(skips):
+                raise ValueError("expected %d ControlNet residuals" % len(skips))
+            # unet.py:567-576; residuals with b=1 broadcast over the CFG batch
+            skips = [K.add_bcast(s, r) for s, r in zip(skips, down_residuals)]
+        x = self.mid_block(x, ctx)
+        if mid_residual is not None:
+            x = K.add_bcast(x, mid_residual)
+        for blk in self.up_blocks:
+            n = len(blk.resnets)
+            x = blk(x, skips[-n:], ctx)
+            skips = skips[:-n]
+        x = self.conv_norm_out.run(x, frames_per_stat=ctx.gn_frames_per_stat, act=K.ACT_SILU)
+        return self.conv_out.run(x, out_f32=True)
+
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, class_labels=None,
+                attention_mask=None, return_dict: bool = True, down_block_additional_residuals=None,
+                mid_block_additional_residual=None, timestep_cond=None, cross_attention_kwargs=None,
+                nhwc_out: bool = False):
+        if class_labels is not None or attention_mask is not None:
+            raise NotImplementedError("class_labels / attention_mask are unused on the reference's path")
+        if not sample.is_cuda:
+            raise RuntimeError("UNet3DConditionModel runs on the HIP device only (no CPU fallback)")
+        device = sample.device
+        self._ensure_ready(device)
+        b, c, f, h, w = sample.shape
+        down = None
+        if down_block_additional_residuals is not None:
+            down = [self._to_nhwc(r, device) for r in down_block_additional_residuals]
+        mid = None if mid_block_additional_residual is None else self._to_nhwc(mid_block_additional_residual, device)
+        eps = self.forward_nhwc(self._to_nhwc(sample, device, self.conv_in.cin_pad), b, f, timestep, encoder_hidden_states,
+                                down, mid, timestep_cond)
+        if nhwc_out:
+            return eps
+        out = K.nhwc_to_ncfhw_f32(eps, b, self.config.out_channels, f)
+        if sample.dtype != torch.float32:
+            out = out.to(sample.dtype)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)
+
+    # ---------------------------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, config: dict, **kwargs) -> "UNet3DConditionModel":
+        merged = {k: v for k, v in dict(config).items() if not k.startswith("_")}
+        merged.update(kwargs)
+        return cls(**merged)
+
+    @classmethod
+    def from_pretrained_2d(cls, pretrained_model_path, use_safetensors=False, subfolder=None, unet_additional_kwargs=None):
+        """Same contract as the reference (unet.py:623-669): read the 2-D SD config.json, force the 3-D
+        block types, build, then load the 2-D weights non-strictly (motion modules stay at init)."""
+        if subfolder is not None:
+            pretrained_model_path = os.path.join(pretrained_model_path, subfolder)
+        config_file = os.path.join(pretrained_model_path, "config.json")
+        if not os.path.isfile(config_file):
+            raise RuntimeError(f"{config_file} does not exist")
+        with open(config_file, "r") as fh:
+            config = json.load(fh)
+        config["down_block_types"] = ["CrossAttnDownBlock3D"] * 3 + ["DownBlock3D"]
+        config["up_block_types"] = ["UpBlock3D"] + ["CrossAttnUpBlock3D"] * 3
+        model = cls.from_config(config, **(unet_additional_kwargs or {}))
+        name = "diffusion_pytorch_model.safetensors" if use_safetensors else "diffusion_pytorch_model.bin"
+        model_file = os.path.join(pretrained_model_path, name)
+        if not os.path.isfile(model_file):
+            raise RuntimeError(f"{model_file} does not exist")
+        if use_safetensors:
+            from safetensors.torch import load_file
+            state_dict = load_file(model_file, device="cpu")
+        else:
+            state_dict = torch.load(model_file, map_location="cpu")
+        m, u = model.load_state_dict(state_dict, strict=False)
+        print(f"### missing keys: {len(m)}; \n### unexpected keys: {len(u)};")
+        params = [p.numel() if "temporal" in n else 0 for n, p in model.named_parameters()]
+        print(f"### Temporal Module Parameters: {len(params)} -> {sum(params) / 1e6} M")
+        return model

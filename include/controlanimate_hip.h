@@ -200,8 +200,10 @@ int ca_layernorm(const ca_layernorm_args* args, void* stream);
  * Addressing (element offsets): for batch z (0 <= z < batches):
  *   zo = z / inner_count, zi = z % inner_count
  *   Q row i  at q + zo*q_outer + zi*q_inner + i*q_row + head*head_dim   (same scheme for O)
- *   z' = z / kv_div; K row j at k + (z'/kv_inner_count)*k_outer + (z'%kv_inner_count)*k_inner
+ *   z' = (z / kv_div) % kv_mod; K row j at k + (z'/kv_inner_count)*k_outer + (z'%kv_inner_count)*k_inner
  *                                   + j*k_row + head*head_dim   (same for V with v pointer)
+ * kv_mod reproduces the reference's ControlNet prompt tiling torch.cat([embeds]*frame_count)
+ * (modules/controlresiduals_pipeline.py:292: image z reads embeds[z % b]); pass kv_mod = batches when unused.
  * head_dim multiple of 8, <= 160.
  * ------------------------------------------------------------------------------------ */
 typedef struct ca_attn_args {
@@ -209,7 +211,7 @@ typedef struct ca_attn_args {
   int64_t q_outer, q_inner, q_row;
   int64_t o_outer, o_inner, o_row;
   int64_t k_outer, k_inner, k_row;   /* shared by K and V */
-  int32_t inner_count, kv_inner_count, kv_div;
+  int32_t inner_count, kv_inner_count, kv_div, kv_mod;
   int32_t batches, heads, head_dim;
   int32_t nq, nk;
   float scale;          /* softmax scale (head_dim^-0.5) */
