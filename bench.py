@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Benchmark of the denoising-loop hot path (BASELINE.json metric: frames/sec + sec/denoise-step).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE iteration of the reference's denoising loop
+(animatediff/pipelines/controlanimation_pipeline.py:790-855) on one 16-frame window:
+ControlNet residuals + UNet3D eps (CFG batch 2) + fused CFG combine / scheduler update.
+Workload at N=1 (BASELINE.json configs[1]): SD1.5 + mm_sd_v15_v2, 16 frames, 512x512 (latent 64x64),
+20 diffusers-LCM steps, guidance 1.1 (CFG on), 1 ControlNet (canny-shaped hints), synthetic seeded
+weights/inputs (no checkpoints exist offline).  Every rank runs its own window (windows are the
+sharding unit, weak scaling); weights are broadcast once over RCCL before timing.
+
+frames/sec = n_gpus * frames_per_window / (steps_per_window * sec_per_step), steps_per_window = 20.
+Prints one JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STEPS_PER_WINDOW = 20
+PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=512, help="frame height = width in pixels")
+    ap.add_argument("--controlnets", type=int, default=1)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def randomize_zero_init_(model, std=0.02, seed=0):
+    """Real checkpoints are non-zero where the architecture zero-initialises (motion proj_out,
+    ControlNet zero-convs): all-zero operands would also let the chip clock higher (DVFS)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for p in model.parameters():
+        if p.numel() and float(p.detach().abs().max()) == 0.0 and p.dim() > 1:
+            p.data.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
+
+
+class KernelTimer:
+    """HIP-event timing of every ca_gemm / ca_conv3x3 launch (events are recorded on the stream the
+    kernels are launched on: torch's current stream) + the algorithmic FLOPs of each launch."""
+
+    def __init__(self):
+        self.records = []  # (variant, flops, start_event, end_event)
+        self.enabled = False
+
+    def install(self):
+        from controlanimate_amd import kernels as K
+        gemm0, conv0 = K.gemm, K.conv3x3
+        timer = self
+
+        def gemm(a, w, **kw):
+            if not timer.enabled:
+                return gemm0(a, w, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = gemm0(a, w, **kw)
+            e.record()
+            m, n, k = a.shape[0], w.shape[0], w.shape[1]
+            timer.records.append((f"gemm_{'128x128' if n % 128 == 0 else '128x64'}", 2.0 * m * n * k, s, e))
+            return out
+
+        def conv3x3(x, w, **kw):
+            if not timer.enabled:
+                return conv0(x, w, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = conv0(x, w, **kw)
+            e.record()
+            n = w.shape[0]
+            mrows = out.shape[0] * out.shape[1] * out.shape[2]
+            timer.records.append((f"conv3x3_{'128x128' if n % 128 == 0 else '128x64'}", 2.0 * mrows * n * 9 * w.shape[3], s, e))
+            return out
+
+        K.gemm, K.conv3x3 = gemm, conv3x3
+
+    def summary(self):
+        agg = {}
+        for name, flops, s, e in self.records:
+            d = agg.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += s.elapsed_time(e)
+        for d in agg.values():
+            d["avg_us"] = 1e3 * d["ms"] / d["launches"]
+            d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        return agg
+
+
+def build_models(args, device, dtype):
+    from controlanimate_amd.configs import controlnet_config, unet_config
+    from controlanimate_amd.controlnet import ControlNetModel
+    from controlanimate_amd.unet import UNet3DConditionModel
+    torch.manual_seed(0)
+    with torch.device(device):
+        unet = UNet3DConditionModel.from_config(unet_config("v2"))
+        nets = [ControlNetModel.from_config(controlnet_config()) for _ in range(args.controlnets)]
+    randomize_zero_init_(unet, seed=1)
+    for i, n in enumerate(nets):
+        randomize_zero_init_(n, seed=2 + i)
+    unet.prepare(device, dtype)
+    for n in nets:
+        n.prepare(device, dtype)
+    return unet, nets
+
+
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))  # >32 threads only adds synchronisation overhead at these op sizes
+
+
+def cpu_baseline(threads: int):
+    """The oracle (fp32 restatement of the reference, oracle/) timed on the host cores on a bounded
+    sample: ONE UNet3D forward at the config-1 shape (2,4,8,32,32), L=77, mm v1 -- the same probe as
+    BASELINE.md section 2 (reference's own code: 8.35 s on 8 cores)."""
+    from oracle.unet3d import UNet3DConfig, init_unet3d_weights, unet3d_forward
+    torch.set_num_threads(threads)
+    cfg = UNet3DConfig.v1()
+    w = init_unet3d_weights(cfg, seed=0)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 8, 32, 32, generator=g)
+    ehs = torch.randn(2, 77, 768, generator=g) * 0.5
+    with torch.no_grad():
+        t0 = time.time()
+        unet3d_forward(w, cfg, x, 500, ehs)
+        dt = time.time() - t0
+    flops = 4.09e12
+    return {"value": 8.0 / (4 * dt), "unit": "frames/s (config-1 shape: 8 frames 256x256, 4 DDIM steps, UNet3D only)",
+            "cores": threads, "kind": "port", "sec_per_step": dt, "tflops": flops / dt / 1e12,
+            "sample": "1 oracle UNet3D forward (2,4,8,32,32) fp32, mm v1, = 1 denoise step of BASELINE config 1 (4.09 TFLOP); "
+                      "config-2 step is 44.6 TFLOP => FLOP-scaled estimate %.1f s/step" % (dt * 44.6 / 4.09)}
+
+
+def main():
+    args = parse()
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd import window_shard as WS
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.schedulers import DiffusersLCMScheduler
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+
+    rank, world, local_rank = WS.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+
+    timer = KernelTimer()
+    if not args.no_roofline:
+        timer.install()
+    unet, nets = build_models(args, device, dtype)
+    bytes_bcast = WS.broadcast_weights([unet.arena.buffer] + [n.arena.buffer for n in nets])
+
+    f, hw = args.frames, args.size // 8
+    g = torch.Generator().manual_seed(1234)
+    latents = torch.randn(1, 4, f, hw, hw, generator=g).to(device)
+    pos = (torch.randn(1, 77, 768, generator=g) * 0.5).to(device)
+    neg = (torch.randn(1, 77, 768, generator=g) * 0.5).to(device)
+    prompt = torch.cat([neg, pos]).contiguous()
+    guidance = 1.1
+    cn = None
+    if nets:
+        cn = MultiControlNetResidualsPipeline([f"synthetic-canny-{i}" for i in range(len(nets))], [1.0] * len(nets), use_lcm=False,
+                                              controlnets=nets, device=device)
+        hints = torch.rand(f, 3, args.size, args.size, generator=g)
+        cn.prep_control_images([h for h in hints], do_classifier_free_guidance=True, guess_mode=False)
+    sched = DiffusersLCMScheduler(**NOISE_SCHEDULER_KWARGS)
+    sched.set_timesteps(STEPS_PER_WINDOW)
+    cpad = unet.conv_in.cin_pad
+    noise_dev = torch.randn(1, 4, f, hw, hw, generator=g).to(device)
+
+    state = {"latents": latents}
+
+    def step(i):
+        idx = i % STEPS_PER_WINDOW
+        t = sched.timesteps[idx]
+        x = K.latents_to_nhwc(state["latents"], cpad, 2, sched.input_scale(idx), dtype)
+        down = mid = None
+        if cn is not None:
+            down, mid = cn.residuals_nhwc(x, t, prompt, False)
+        eps = unet.forward_nhwc(x, 2, f, t, prompt, down, mid)
+        coef, clip = sched.coefficients(idx)
+        state["latents"], _ = K.cfg_scheduler_step(eps, 2, guidance, state["latents"], noise_dev, coef, clip)
+        if idx == STEPS_PER_WINDOW - 1:
+            state["latents"] = latents  # next window
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    timer.enabled = not args.no_roofline
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if not torch.isfinite(state["latents"]).all():
+        raise SystemExit("non-finite latents after the timed region")
+
+    sec_per_step = elapsed / args.steps
+    fps = world * f / (STEPS_PER_WINDOW * sec_per_step)
+    unet_tflop = 35.53 * (f / 16) * (args.size / 512) ** 2  # BASELINE.md section 3 (config 2; attention terms scale slightly faster)
+    cn_tflop = 9.07 * (f / 16) * (args.size / 512) ** 2
+    step_tflop = unet_tflop + len(nets) * cn_tflop
+    out = {
+        "metric": "frames_per_sec", "value": round(fps, 4), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * sec_per_step, 3),
+        "sec_per_denoise_step": round(sec_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"SD1.5+mm_sd_v15_v2 UNet3D, {f} frames {args.size}x{args.size}, {STEPS_PER_WINDOW} LCM steps/window, "
+                               f"CFG g={guidance} (batch 2), {len(nets)} ControlNet(s); one window per GPU",
+                   "frames_per_window": f, "steps_per_window": STEPS_PER_WINDOW, "controlnets": len(nets),
+                   "parallelism": f"window-shard x{world}" if world > 1 else "single GPU",
+                   "weight_broadcast_bytes": bytes_bcast},
+        "step_algorithmic_tflop": round(step_tflop, 2),
+        "step_mfma_frac": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
+    }
+    if not args.no_roofline:
+        agg = timer.summary()
+        if agg:
+            dom = max(agg, key=lambda k: agg[k]["ms"])
+            d = agg[dom]
+            out["roofline"] = {"bound": "mfma", "kernel": f"k_gemm<{dom}>", "achieved": round(d["tflops"], 2), "peak": PEAK_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                               "launches": d["launches"], "avg_launch_us": round(d["avg_us"], 2),
+                               "flop_per_launch": round(d["flops"] / d["launches"], 1),
+                               "share_of_step_time": round(d["ms"] * 1e-3 / elapsed, 4)}
+            out["kernel_family"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2),
+                                        "time_share": round(v["ms"] * 1e-3 / elapsed, 4)} for k, v in sorted(agg.items())}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(usable_cores())
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,10 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime: it must be loaded FIRST so that this library binds to the
+    # same libamdhip64 instance (otherwise the process ends up with two runtimes and launches from
+    # here fail with "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CAHipUnavailable(
             f"{LIB_PATH} is missing: the HIP extension is not built. Run "

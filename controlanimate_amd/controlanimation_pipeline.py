@@ -1,0 +1,241 @@
+"""ControlAnimationPipeline: prompt/IP embeds, timesteps, initial latents and the DENOISING LOOP.
+
+Call surface of the reference's animatediff/pipelines/controlanimation_pipeline.py
+(ctor :76-92, __call__ :626-663 -> AnimationPipelineOutput(videos)); loop semantics of :790-855:
+
+  per step   ControlNet input selection (:811-813)  ->  MultiControlNetResidualsPipeline
+             UNet3D eps (CFG batch b=2 unless native LCM)                       (:821-841)
+             CFG combine + scheduler update, ONE fused kernel (:844-849 / :833)
+  skipped    torch.cuda.empty_cache() every step (:794) -- allocator flush + sync, no output effect.
+
+Out of scope in this round (SURVEY 8f "next"): VAE encode/decode and the CLIP text encoder.  The
+pipeline therefore takes `prompt_embeds` / `negative_prompt_embeds` (as the reference's facade
+already does, modules/controlanimate_pipeline.py:133-146); if a `vae` object with the diffusers
+AutoencoderKL interface is supplied it is used for encode/decode exactly where the reference does,
+otherwise frames are exchanged as latents (`input_latents`, `last_output_latents`,
+`output_type="latent"`).
+RNG parity: initial latents come from the caller's CPU torch.Generator; the in-tree LCM
+sampler draws its per-step noise from the GLOBAL CPU RNG (:1601), diffusers' LCM from the generator.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from .controlresiduals_pipeline import MultiControlNetResidualsPipeline, _image_to_chw01
+from .schedulers import DiffusersLCMScheduler, LCMScheduler, get_w_embedding
+
+
+@dataclass
+class AnimationPipelineOutput:
+    videos: Union[torch.Tensor, np.ndarray]
+
+
+class ControlAnimationPipeline:
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler=None):
+        if scheduler is None:  # native LCM (reference :95-101)
+            scheduler = LCMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", prediction_type="epsilon")
+        self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
+        self.vae_scale_factor = 8
+        self.ip_adapter = None
+        self.device = torch.device("cuda")
+        self.last_step_times: List[float] = []
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self.unet.to(self.device)
+        if hasattr(self.vae, "to"):
+            self.vae.to(self.device)
+        return self
+
+    @property
+    def _execution_device(self):
+        return self.device
+
+    def enable_xformers_memory_efficient_attention(self):
+        """No-op: the flash attention kernel is the only attention path (no xformers)."""
+
+    def get_w_embedding(self, w, embedding_dim=512, dtype=torch.float32):
+        return get_w_embedding(w, embedding_dim, dtype)
+
+    def get_timesteps(self, num_inference_steps, strength, device=None):
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        return self.scheduler.timesteps[t_start * self.scheduler.order:], num_inference_steps - t_start
+
+    # ------------------------------------------------------------------------------------------
+    def _encode_frames(self, frames, generator) -> List[torch.Tensor]:
+        if self.vae is None:
+            raise RuntimeError("frames given as images need a `vae` (VAE encode is a 'next' component); pass latents instead")
+        out = []
+        for fr in frames:
+            img = (_image_to_chw01(fr) * 2.0 - 1.0)[None].to(self.device)
+            lat = self.vae.encode(img).latent_dist.sample(generator)
+            out.append(self.vae.config.scaling_factor * lat.float())
+        return out
+
+    def prepare_latents(self, input_frames, batch_size, num_channels_latents, video_length, height, width, dtype, device,
+                        generator, latent_timestep, overlaps, strength, latents=None, last_output_frames=None, use_lcm=False,
+                        use_img2img=False, input_latents=None, last_output_latents=None):
+        """Reference :549-613. Returns fp32 [1,4,f,h/8,w/8] on `device`. `input_latents` [1,4,f,h,w] /
+        `last_output_latents` [1,4,n,h,w] replace the per-frame VAE encodes when no VAE is attached."""
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        noise = torch.randn(shape, generator=generator, dtype=torch.float32)  # randn_tensor with a CPU generator
+        latents = noise.clone()
+        if overlaps > 0 or strength < 1 or use_lcm:
+            frames_lat = None
+            if input_latents is not None:
+                frames_lat = [input_latents[:, :, i].float().cpu() for i in range(input_latents.shape[2])]
+            elif input_frames is not None and self.vae is not None:
+                frames_lat = [x.cpu() for x in self._encode_frames(input_frames, generator)]
+            last_lat = None
+            if last_output_latents is not None:
+                last_lat = [last_output_latents[:, :, i].float().cpu() for i in range(last_output_latents.shape[2])]
+            elif last_output_frames is not None and self.vae is not None:
+                last_lat = [x.cpu() for x in self._encode_frames(last_output_frames, generator)]
+            if use_lcm:
+                if frames_lat is None:
+                    raise RuntimeError("native LCM starts from the input frames' latents (reference :590-592)")
+                latents = self.scheduler.add_noise(torch.stack(frames_lat, dim=2), latents, latent_timestep)
+            elif last_lat is not None and strength < 1.0:
+                for i in range(video_length):
+                    if i < len(last_lat):
+                        src = last_lat[i]
+                    elif not use_img2img:
+                        src = last_lat[-1]
+                    else:
+                        src = frames_lat[i]
+                    latents[:, :, i] = self.scheduler.add_noise(src, latents[:, :, i], latent_timestep)
+        if strength >= 1 and not use_lcm:
+            latents = latents * self.scheduler.init_noise_sigma
+        return latents.to(device)
+
+    def decode_latents(self, latents):
+        if self.vae is None:
+            raise RuntimeError("no vae attached: request output_type='latent'")
+        video_length = latents.shape[2]
+        latents = 1 / self.vae.config.scaling_factor * latents
+        frames = [self.vae.decode(latents[:, :, i]).sample for i in range(video_length)]
+        video = torch.stack(frames, dim=2)
+        return (video / 2 + 0.5).clamp(0, 1).cpu().float().numpy()
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, video_length: Optional[int], input_frames: list = None, prompt=None, height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, strength: float = 0.5, guidance_scale: float = 7.5,
+                 negative_prompt=None, num_videos_per_prompt: Optional[int] = 1, eta: float = 0.0,
+                 generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
+                 output_type: Optional[str] = "tensor", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: Optional[int] = 1,
+                 overlaps: int = 0, multicontrolnetresiduals_pipeline: Optional[MultiControlNetResidualsPipeline] = None,
+                 multicontrolnetresiduals_overlap_pipeline=None, num_images_per_prompt: Optional[int] = 1, clip_skip=None,
+                 cross_attention_kwargs: Optional[Dict[str, Any]] = None, prompt_embeds: Optional[torch.Tensor] = None,
+                 negative_prompt_embeds: Optional[torch.Tensor] = None, epoch=0, output_dir="tmp/output", save_outputs=False,
+                 last_output_frames=None, use_lcm=True, lcm_origin_steps: int = 50, guess_mode=False, ipa_scale=0.4,
+                 use_img2img=True, input_latents: Optional[torch.Tensor] = None,
+                 last_output_latents: Optional[torch.Tensor] = None, control_images=None, **kwargs):
+        unet = self.unet
+        sample_size = unet.config.get("sample_size") or 64
+        height = height or sample_size * self.vae_scale_factor
+        width = width or sample_size * self.vae_scale_factor
+        if height % 8 or width % 8:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        device = self.device
+        do_cfg = guidance_scale > 1.0
+        if prompt_embeds is None or (do_cfg and negative_prompt_embeds is None):
+            raise RuntimeError("pass prompt_embeds / negative_prompt_embeds (the CLIP text encoder is a 'next' component)")
+        prompt_embeds = prompt_embeds.to(device).float()
+        negative_prompt_embeds = None if negative_prompt_embeds is None else negative_prompt_embeds.to(device).float()
+        if negative_prompt_embeds is None:
+            negative_prompt_embeds = torch.zeros_like(prompt_embeds)
+
+        # IP-Adapter tokens (:698-710)
+        if self.ip_adapter is not None:
+            if last_output_frames is not None or kwargs.get("clip_image_embeds") is not None:
+                img_tok, uncond_tok = self.ip_adapter.get_image_embeds_4controlanimate(
+                    pil_image=None if last_output_frames is None else last_output_frames[0], scale=ipa_scale,
+                    clip_image_embeds=kwargs.get("clip_image_embeds"))
+                prompt_embeds = torch.cat([prompt_embeds, img_tok.to(device).float()], dim=1)
+                negative_prompt_embeds = torch.cat([negative_prompt_embeds, uncond_tok.to(device).float()], dim=1)
+            else:
+                z = torch.zeros((1, 4, prompt_embeds.shape[-1]), device=device)
+                prompt_embeds = torch.cat([prompt_embeds, z], dim=1)
+                negative_prompt_embeds = torch.cat([negative_prompt_embeds, z], dim=1)
+        lcm_prompt_embeds = prompt_embeds.contiguous()
+        cfg_prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds]).contiguous() if do_cfg else lcm_prompt_embeds
+
+        # timesteps (:731-740)
+        sched = self.scheduler
+        native_lcm = use_lcm or (isinstance(sched, LCMScheduler) and not isinstance(sched, DiffusersLCMScheduler))
+        if native_lcm:
+            sched.set_timesteps(strength, num_inference_steps, lcm_origin_steps)
+        else:
+            sched.set_timesteps(num_inference_steps, device=device)
+        first = 0
+        if strength >= 1 or use_lcm:
+            timesteps = sched.timesteps
+        else:
+            timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, device)
+            first = len(sched.timesteps) - len(timesteps)
+
+        if latents is None:
+            latents = self.prepare_latents(input_frames, 1, unet.in_channels, video_length, height, width, torch.float32, device,
+                                           generator, timesteps[:1], overlaps, strength, None, last_output_frames, use_lcm,
+                                           use_img2img, input_latents, last_output_latents)
+        latents = latents.to(device=device, dtype=torch.float32).contiguous()
+        f = latents.shape[2]
+
+        w_embedding = get_w_embedding(torch.tensor([float(guidance_scale)]), embedding_dim=256).to(device) if use_lcm else None
+
+        cn = multicontrolnetresiduals_pipeline
+        if cn is not None:
+            ctrl = control_images if control_images is not None else input_frames
+            cn.prep_control_images(ctrl, control_image_processor=None, epoch=epoch, output_dir=output_dir,
+                                   save_outputs=save_outputs, do_classifier_free_guidance=do_cfg, guess_mode=guess_mode)
+            if len(cn.prep_images[0]) % f:
+                raise ValueError("number of control images must equal the number of frames")
+        cn_single = use_lcm or guess_mode or not do_cfg  # (:811-813)
+        cpad = unet.conv_in.cin_pad
+        rep = 1 if use_lcm else (2 if do_cfg else 1)
+        unet_prompt = lcm_prompt_embeds if use_lcm else cfg_prompt_embeds
+        cn_prompt = lcm_prompt_embeds if cn_single else cfg_prompt_embeds
+        denoised = None
+        self.last_step_times = []
+        for i, t in enumerate(timesteps):
+            idx = first + i
+            in_scale = sched.input_scale(idx)
+            x = K.latents_to_nhwc(latents, cpad, rep, in_scale, unet.act_dtype)          # [(rep f), h, w, 8]
+            down = mid = None
+            if cn is not None:
+                x_cn = x if (rep == 1 or not cn_single) else x[:f]
+                down, mid = cn.residuals_nhwc(x_cn, t, cn_prompt, guess_mode)
+            eps = unet.forward_nhwc(x, rep, f, t, unet_prompt, down, mid, timestep_cond=w_embedding)
+            coef, clip = sched.coefficients(idx)
+            noise = None
+            if sched.needs_noise and len(sched.timesteps) > 1:
+                if isinstance(sched, DiffusersLCMScheduler):
+                    noise = torch.randn(latents.shape, generator=generator, dtype=torch.float32)
+                else:
+                    noise = torch.randn(latents.shape)  # global CPU RNG, as the reference (:1601)
+                noise = noise.to(device)
+            latents, den = K.cfg_scheduler_step(eps, rep, guidance_scale if rep == 2 else 1.0, latents, noise, coef, clip,
+                                                want_denoised=use_lcm)
+            if use_lcm:
+                denoised = den
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, latents)
+        final = denoised if use_lcm else latents
+        if output_type == "latent" or self.vae is None:
+            video = final
+        else:
+            video = self.decode_latents(final)
+            if output_type == "tensor":
+                video = torch.from_numpy(video)
+        if not return_dict:
+            return video
+        return AnimationPipelineOutput(videos=video)

@@ -1,0 +1,107 @@
+"""MultiControlNetResidualsPipeline: the ControlNet stack of the denoising loop, on HIP kernels.
+
+Same call surface as the reference's modules/controlresiduals_pipeline.py:
+    MultiControlNetResidualsPipeline(hf_controlnet_names, cond_scale, use_lcm)            (:25-38)
+    .prep_control_images(images, control_image_processor, epoch, output_dir, save_outputs,
+                         do_classifier_free_guidance, guess_mode)  -> self.prep_images     (:226-273)
+    .__call__(control_model_input[b,4,f,h,w], t, controlnet_prompt_embeds[b,L,768], frame_count,
+              image_embeds=None, do_classifier_free_guidance=True, guess_mode=True)
+        -> (tuple of 12 Tensor[b,C,f,h,w], Tensor[b,1280,f,h/8,w/8])                       (:278-316)
+    attributes .controlnet (.nets, .half(), .dtype), .controlnets, .cond_scale, .controlnet_names.
+
+The returned residuals are [b,C,f,h,w] VIEWS of channels-last storage, which the UNet consumes
+without a copy (unet.py `_to_nhwc`).  Annotators (canny / openpose / ... detectors,
+reference :97-150) are third-party pre-processing outside the loop and are NOT rebuilt: pass
+already-annotated control images, or plug callables in through `annotators`.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from .controlnet import ControlNetModel, MultiControlNetModel
+
+
+def _image_to_chw01(img) -> torch.Tensor:
+    """PIL.Image / ndarray HWC uint8 / tensor -> float32 [3,H,W] in [0,1] (VaeImageProcessor with
+    do_normalize=False, controlanimation_pipeline.py:160-163)."""
+    if torch.is_tensor(img):
+        t = img.float()
+        if t.dim() == 4:
+            t = t[0]
+        return t
+    arr = np.asarray(img)
+    if arr.ndim == 2:
+        arr = np.stack([arr] * 3, axis=-1)
+    t = torch.from_numpy(arr[..., :3].copy()).permute(2, 0, 1).float()
+    return t / 255.0 if arr.dtype == np.uint8 else t
+
+
+class MultiControlNetResidualsPipeline:
+    def __init__(self, hf_controlnet_names: Sequence[str], cond_scale: Sequence[float], use_lcm: bool,
+                 controlnets: Optional[Sequence[ControlNetModel]] = None, device="cuda",
+                 annotators: Optional[Dict[str, Callable]] = None):
+        self.controlnet_names = list(hf_controlnet_names)
+        if controlnets is None:
+            raise RuntimeError(
+                "no ControlNet weights: pass `controlnets=[ControlNetModel, ...]` (checkpoint loading from the "
+                "Hugging Face hub needs network access, which this build does not have)")
+        if len(controlnets) != len(self.controlnet_names):
+            raise ValueError("one ControlNetModel per name expected")
+        self.controlnets = list(controlnets)
+        self.controlnet = MultiControlNetModel(self.controlnets).to(device)
+        self.cond_scale = list(cond_scale)
+        self.use_lcm = use_lcm
+        self.ip_adapter = None
+        self.annotators = dict(annotators or {})
+        self.prep_images: Optional[List[torch.Tensor]] = None
+        self.device = torch.device(device)
+
+    # ------------------------------------------------------------------------------------------
+    def prepare_controlnet_input_image(self, controlnet_model: str, image):
+        for key, fn in self.annotators.items():
+            if key in controlnet_model:
+                return fn(image)
+        return image  # already annotated
+
+    def prep_control_images(self, images, control_image_processor=None, epoch=0, output_dir="tmp/output",
+                            save_outputs=False, do_classifier_free_guidance=True, guess_mode=False):
+        """images: list of f control images (PIL / arrays / tensors), or {controlnet name: list} when each
+        net has its own pre-annotated set.  Result: self.prep_images[i] = Tensor[(b f),3,H,W] in [0,1];
+        doubled for CFG exactly when the reference doubles it (:268-269)."""
+        prep = []
+        for name in self.controlnet_names:
+            src = images[name] if isinstance(images, dict) else images
+            frames = [_image_to_chw01(self.prepare_controlnet_input_image(name, im)) for im in src]
+            ctrl = torch.stack(frames).to(self.device)
+            if do_classifier_free_guidance and not guess_mode and not self.use_lcm:
+                ctrl = torch.cat([ctrl] * 2)
+            prep.append(ctrl)
+        self.prep_images = prep
+
+    # ------------------------------------------------------------------------------------------
+    def residuals_nhwc(self, x_nhwc: torch.Tensor, t, controlnet_prompt_embeds: torch.Tensor, guess_mode: bool):
+        """x_nhwc: [(b f),h,w,8] -> (12 NHWC residuals, mid), summed over the nets."""
+        if self.prep_images is None:
+            raise RuntimeError("call prep_control_images() first")
+        return self.controlnet.forward_nhwc(x_nhwc, t, controlnet_prompt_embeds, self.prep_images, self.cond_scale, guess_mode)
+
+    @torch.no_grad()
+    def __call__(self, control_model_input: torch.Tensor, t, controlnet_prompt_embeds: torch.Tensor, frame_count: int,
+                 image_embeds=None, do_classifier_free_guidance=True, guess_mode=True):
+        b, c, f, h, w = control_model_input.shape
+        if f != frame_count:
+            raise ValueError("frame_count must equal the number of latent frames (SURVEY App. C-11)")
+        net0 = self.controlnets[0]
+        net0._ensure_ready(control_model_input.device)
+        x = K.ncfhw_to_nhwc(control_model_input, net0.conv_in.cin_pad, net0.act_dtype)
+        down, mid = self.residuals_nhwc(x, t, controlnet_prompt_embeds, guess_mode)
+
+        def to5(tn):  # [(b f),h,w,C] -> [b,C,f,h,w] view (no copy)
+            bf, hh, ww, cc = tn.shape
+            return tn.view(bf // frame_count, frame_count, hh, ww, cc).permute(0, 4, 1, 2, 3)
+
+        return tuple(to5(d) for d in down), to5(mid)
