@@ -208,59 +208,118 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int DT>
+// One wave normalises LN_RPW rows per iteration: all their loads are issued before the first
+// reduction (memory-level parallelism; a single 640-byte row per wave was latency-bound at
+// 0.8 TB/s), rows stay packed in registers and are unpacked per pass (sum, variance, output).
+constexpr int LN_RPW = 4;
+
+template <int DT, int SLOTS>
 __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int C8 = p.c >> 3;
   const float inv_c = 1.0f / (float)p.c;
-  for (int64_t row = wave; row < p.rows; row += nwaves) {
-    float f[LN_MAX_SLOTS][8];
-    float s = 0.f;
+  bool cok[SLOTS];
 #pragma unroll
-    for (int k = 0; k < LN_MAX_SLOTS; ++k) {
-      const int c8 = lane + 64 * k;
-      if (c8 < C8) {
-        unpack8<DT>(ld16(p.x + row * p.c + (c8 << 3)), f[k]);
+  for (int k = 0; k < SLOTS; ++k) cok[k] = lane + 64 * k < C8;
+  for (int64_t row0 = wave * LN_RPW; row0 < p.rows; row0 += nwaves * LN_RPW) {
+    u32x4 raw[LN_RPW][SLOTS];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += f[k][j];
+    for (int r = 0; r < LN_RPW; ++r) {
+      const int64_t row = row0 + r;
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k) {
+        raw[r][k] = (cok[k] && row < p.rows) ? ld16(p.x + row * p.c + ((lane + 64 * k) << 3)) : (u32x4){0u, 0u, 0u, 0u};
       }
     }
-    const float mean = wave_sum(s) * inv_c;
-    float q = 0.f;
+    float mean[LN_RPW], rstd[LN_RPW];
 #pragma unroll
-    for (int k = 0; k < LN_MAX_SLOTS; ++k) {
-      const int c8 = lane + 64 * k;
-      if (c8 < C8) {
+    for (int r = 0; r < LN_RPW; ++r) {
+      float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float d = f[k][j] - mean;
-          q += d * d;
+      for (int k = 0; k < SLOTS; ++k) {
+        float f[8];
+        unpack8<DT>(raw[r][k], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += f[j];
+      }
+      mean[r] = s;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+      for (int r = 0; r < LN_RPW; ++r) mean[r] += __shfl_xor(mean[r], off);
+    }
+#pragma unroll
+    for (int r = 0; r < LN_RPW; ++r) {
+      mean[r] *= inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k) {
+        float f[8];
+        unpack8<DT>(raw[r][k], f);
+        if (cok[k]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = f[j] - mean[r];
+            q += d * d;
+          }
         }
       }
-    }
-    const float rstd = rsqrtf(wave_sum(q) * inv_c + p.eps);
-    const float* pos = nullptr;
-    if (p.pos) {
-      const int64_t fr = (row / p.rows_per_frame) % p.frames;
-      pos = p.pos + fr * p.c;
+      rstd[r] = q;
     }
 #pragma unroll
-    for (int k = 0; k < LN_MAX_SLOTS; ++k) {
-      const int c8 = lane + 64 * k;
-      if (c8 < C8) {
-        const int ch = c8 << 3;
-        float o[8];
+    for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float v = (f[k][j] - mean) * rstd * p.gamma[ch + j] + p.beta[ch + j];
-          if (pos) v += pos[ch + j];
-          o[j] = v;
+      for (int r = 0; r < LN_RPW; ++r) rstd[r] += __shfl_xor(rstd[r], off);
+    }
+#pragma unroll
+    for (int r = 0; r < LN_RPW; ++r) rstd[r] = rsqrtf(rstd[r] * inv_c + p.eps);
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+      if (!cok[k]) continue;
+      const int ch = (lane + 64 * k) << 3;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + ch), g1 = *reinterpret_cast<const f32x4*>(p.gamma + ch + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + ch), b1 = *reinterpret_cast<const f32x4*>(p.beta + ch + 4);
+#pragma unroll
+      for (int r = 0; r < LN_RPW; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= p.rows) continue;
+        float f[8], o[8];
+        unpack8<DT>(raw[r][k], f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = (f[j] - mean[r]) * rstd[r] * g0[j] + b0[j];
+          o[j + 4] = (f[j + 4] - mean[r]) * rstd[r] * g1[j] + b1[j];
+        }
+        if (p.pos) {
+          const float* pos = p.pos + ((row / p.rows_per_frame) % p.frames) * p.c + ch;
+          const f32x4 p0 = *reinterpret_cast<const f32x4*>(pos), p1 = *reinterpret_cast<const f32x4*>(pos + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] += p0[j];
+            o[j + 4] += p1[j];
+          }
         }
         st16(p.y + row * p.c + ch, pack8<DT>(o));
       }
     }
+  }
+}
+
+template <int DT>
+void launch_layernorm(const LnParams& p, hipStream_t st) {
+  int64_t waves = (p.rows + LN_RPW - 1) / LN_RPW;
+  int64_t blocks = (waves + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  const int slots = (p.c / 8 + 63) / 64;
+  dim3 grid((unsigned)blocks), block(256);
+  switch (slots) {
+    case 1: hipLaunchKernelGGL((k_layernorm<DT, 1>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_layernorm<DT, 2>), grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL((k_layernorm<DT, 3>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((k_layernorm<DT, 4>), grid, block, 0, st, p); break;
   }
 }
 
@@ -313,10 +372,8 @@ extern "C" int ca_layernorm(const ca_layernorm_args* a, void* stream) {
   p.rows_per_frame = a->rows_per_frame > 0 ? a->rows_per_frame : 1;
   p.frames = a->frames > 0 ? a->frames : 1;
   p.eps = a->eps;
-  int64_t blocks = (a->rows + 3) / 4;
-  if (blocks > 8192) blocks = 8192;
-  if (a->dtype == CA_BF16) hipLaunchKernelGGL(k_layernorm<CA_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(k_layernorm<CA_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  if (a->dtype == CA_BF16) launch_layernorm<CA_BF16>(p, (hipStream_t)stream);
+  else launch_layernorm<CA_F16>(p, (hipStream_t)stream);
   CA_CHECK_LAUNCH("ca_layernorm");
   return CA_OK;
 }

@@ -1,0 +1,161 @@
+"""IP-Adapter plumbing for the HIP UNet: processor installation, checkpoint key renumbering,
+scale, image-token projection.
+
+Follows the reference's modules/ip_adapter.py:
+  set_ip_adapter (:95-127)        which processor each attention site gets (IP processors on names
+                                  containing "attn2" outside the motion modules), hidden sizes by block
+  load_ip_adapter (:136-185)      SD1.5 checkpoints number the IP layers 1,3,5,...,31; the reference
+                                  renumbers them by enumerating `unet.attn_processors` and taking the
+                                  positions whose key contains "attn2" -- order down 0-2 (x2), up 1-3
+                                  (x3), mid
+  set_scale (:200-203), ImageProjModel (:30-47), get_image_embeds(_4controlanimate) (:187-222)
+The CLIP vision encoder that produces `clip_image_embeds` [n,1024] runs once per window, not per
+step, and is out of scope: pass an `image_encoder` callable (PIL -> [1,1024]) or
+the embeds themselves.
+"""
+from __future__ import annotations
+
+import re
+from typing import Callable, Dict, Optional
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from .attention_processor import AttnProcessor, CNAttnProcessor, IPAttnProcessor
+from .layers import HipLayerNorm, HipLinear, WeightArena
+
+
+class ImageProjModel(nn.Module):
+    """Linear(clip_dim -> tokens*cross_dim) + LayerNorm(cross_dim): the 4 image-prompt tokens."""
+
+    def __init__(self, cross_attention_dim=1024, clip_embeddings_dim=1024, clip_extra_context_tokens=4):
+        super().__init__()
+        self.cross_attention_dim = cross_attention_dim
+        self.clip_extra_context_tokens = clip_extra_context_tokens
+        self.proj = HipLinear(clip_embeddings_dim, clip_extra_context_tokens * cross_attention_dim)
+        self.norm = HipLayerNorm(cross_attention_dim)
+        self.arena: Optional[WeightArena] = None
+        self.act_dtype = torch.float16
+
+    def prepare(self, device, dtype=None):
+        if dtype is not None:
+            self.act_dtype = dtype
+        arena = WeightArena()
+        self.proj.pack(arena, self.act_dtype)
+        self.norm.pack(arena, self.act_dtype)
+        arena.finalize(device)
+        self.arena = arena
+        return self
+
+    @torch.no_grad()
+    def forward(self, image_embeds: torch.Tensor) -> torch.Tensor:
+        if self.arena is None:
+            self.prepare(image_embeds.device)
+        x = image_embeds.to(self.act_dtype).contiguous()
+        t = self.proj.run(x).view(-1, self.cross_attention_dim)
+        return self.norm.run(t).view(-1, self.clip_extra_context_tokens, self.cross_attention_dim)
+
+
+class IPAdapter:
+    def __init__(self, sd_pipe, image_encoder: Optional[Callable], ip_ckpt, device, num_tokens=4, clip_embeddings_dim=1024):
+        self.device = torch.device(device)
+        self.image_encoder = image_encoder
+        self.ip_ckpt = ip_ckpt
+        self.num_tokens = num_tokens
+        self.pipe = sd_pipe
+        self.set_ip_adapter()
+        self.image_proj_model = ImageProjModel(cross_attention_dim=self.pipe.unet.config.cross_attention_dim,
+                                               clip_embeddings_dim=clip_embeddings_dim,
+                                               clip_extra_context_tokens=num_tokens).to(self.device)
+        if ip_ckpt is not None:
+            self.load_ip_adapter()
+
+    # ---- reference :95-127 --------------------------------------------------------------------
+    def set_ip_adapter(self):
+        unet = self.pipe.unet
+        procs = {}
+        for name in unet.attn_processors.keys():
+            plain = name.endswith("attn1.processor") or "temporal_transformer" in name or "attn" not in name
+            if name.startswith("mid_block"):
+                hidden = unet.config.block_out_channels[-1]
+            elif name.startswith("up_blocks"):
+                hidden = list(reversed(unet.config.block_out_channels))[int(name[len("up_blocks.")])]
+            else:
+                hidden = unet.config.block_out_channels[int(name[len("down_blocks.")])]
+            if plain:
+                procs[name] = AttnProcessor()
+            else:
+                procs[name] = IPAttnProcessor(hidden_size=hidden, cross_attention_dim=unet.config.cross_attention_dim,
+                                              scale=1.0, num_tokens=self.num_tokens).to(self.device)
+        unet.set_attn_processor(procs)
+
+    def set_ip_adapter_4controlanimate(self, pipe):
+        """ControlNets see the same (text + image tokens) context but must ignore the image tokens."""
+        nets = pipe.controlnet.nets if hasattr(pipe.controlnet, "nets") else [pipe.controlnet]
+        for net in nets:
+            net.set_attn_processor(CNAttnProcessor(num_tokens=self.num_tokens))
+
+    # ---- reference :136-185 -------------------------------------------------------------------
+    @staticmethod
+    def renumber_ip_keys(ip_state: Dict[str, torch.Tensor], attn_processor_keys) -> Dict[str, torch.Tensor]:
+        """Checkpoint keys "<n>.to_k_ip.weight" (file order) -> "<index in attn_processors>.to_k_ip.weight"."""
+        numbers = []
+        for i, key in enumerate(attn_processor_keys):
+            if "attn2" in key:
+                numbers += [i, i]
+        out = {}
+        for i, key in zip(numbers, ip_state.keys()):
+            m = re.search(r"\d+", key)
+            new_key = key[:m.start()] + str(i) + key[m.end():] if m else key
+            out[new_key] = ip_state[key]
+        return out
+
+    def load_ip_adapter(self, state_dict: Optional[dict] = None):
+        if state_dict is None:
+            ck = self.ip_ckpt
+            if isinstance(ck, dict):
+                state_dict = ck
+            elif str(ck).endswith(".safetensors"):
+                from safetensors import safe_open
+                state_dict = {"image_proj": {}, "ip_adapter": {}}
+                with safe_open(ck, framework="pt", device="cpu") as fh:
+                    for key in fh.keys():
+                        if key.startswith("image_proj."):
+                            state_dict["image_proj"][key.replace("image_proj.", "")] = fh.get_tensor(key)
+                        elif key.startswith("ip_adapter."):
+                            state_dict["ip_adapter"][key.replace("ip_adapter.", "")] = fh.get_tensor(key)
+            else:
+                state_dict = torch.load(ck, map_location="cpu")
+        self.image_proj_model.load_state_dict(state_dict["image_proj"])
+        self.image_proj_model.arena = None
+        procs = self.pipe.unet.attn_processors
+        new_sd = self.renumber_ip_keys(state_dict["ip_adapter"], procs.keys())
+        layers = nn.ModuleList([p if isinstance(p, nn.Module) else nn.Identity() for p in procs.values()])
+        layers.load_state_dict(new_sd)
+        self.pipe.unet.arena = None  # re-pack with the loaded to_k_ip / to_v_ip
+
+    def set_scale(self, scale):
+        for p in self.pipe.unet.attn_processors.values():
+            if isinstance(p, IPAttnProcessor):
+                p.scale = scale
+
+    # ---- reference :187-222 -------------------------------------------------------------------
+    @torch.no_grad()
+    def get_image_embeds(self, pil_image=None, clip_image_embeds=None):
+        if pil_image is not None:
+            if self.image_encoder is None:
+                raise RuntimeError("no image_encoder attached: pass clip_image_embeds (CLIP vision is out of scope)")
+            clip_image_embeds = self.image_encoder(pil_image)
+        clip_image_embeds = clip_image_embeds.to(self.device)
+        tokens = self.image_proj_model(clip_image_embeds)
+        uncond = self.image_proj_model(torch.zeros_like(clip_image_embeds))
+        return tokens, uncond
+
+    def get_image_embeds_4controlanimate(self, pil_image=None, scale=0.4, num_samples=1, clip_image_embeds=None):
+        self.set_scale(scale)
+        tokens, uncond = self.get_image_embeds(pil_image=pil_image, clip_image_embeds=clip_image_embeds)
+        bs, seq, _ = tokens.shape
+        tokens = tokens.repeat(1, num_samples, 1).view(bs * num_samples, seq, -1)
+        uncond = uncond.repeat(1, num_samples, 1).view(bs * num_samples, seq, -1)
+        return tokens, uncond

@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library builds/loads and exports exactly what include/controlanimate_hip.h
+declares; ctypes struct layouts equal the C layouts (sizeof + every field offset, via gcc)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "controlanimate_hip.h")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from controlanimate_amd import _build, _capi
+    _build.build(verbose=False)
+    return _capi
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ca_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    lib = capi.lib()
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(capi.SYMBOLS) == names, "binding table and header disagree"
+    assert lib.ca_abi_version() == capi.ABI_VERSION
+
+
+def test_ctypes_structs_match_c_layout(capi):
+    structs = {"ca_gemm_args": capi.GemmArgs, "ca_conv_args": capi.ConvArgs, "ca_groupnorm_args": capi.GroupNormArgs,
+               "ca_layernorm_args": capi.LayerNormArgs, "ca_attn_args": capi.AttnArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for cname, st in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "l.c"), os.path.join(d, "l")
+        open(src, "w").write("\n".join(lines))
+        subprocess.check_call(["gcc", "-o", exe, src])
+        out = subprocess.check_output([exe], text=True)
+    got = dict(l.split() for l in out.strip().splitlines())
+    for cname, st in structs.items():
+        assert int(got[cname]) == C.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(st, fname).offset, f"{cname}.{fname}"
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu(capi):
+    """Argument validation happens before any launch: usable as a no-GPU check of the error path."""
+    lib = capi.lib()
+    args = capi.GemmArgs(m=0, n=0, k1=0, k2=0)
+    rc = lib.ca_gemm(C.byref(args), None)
+    assert rc == -1 and b"ca_gemm" in lib.ca_last_error()
+    assert lib.ca_groupnorm_partials_floats(32, 4096, 1, 32) == 32 * 64 * 32 * 2
+    assert lib.ca_groupnorm_partials_floats(2, 4096, 2, 32) == 1 * 128 * 32 * 2
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch):
+    from controlanimate_amd import _capi
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libcontrolanimate_hip.so")
+    with pytest.raises(_capi.CAHipUnavailable):
+        _capi.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under controlanimate_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "controlanimate_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f

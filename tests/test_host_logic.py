@@ -1,0 +1,158 @@
+"""CPU: host-side logic of the product (no kernels): sampler coefficient tables vs the oracle's
+step functions, weight packing layouts, module/key parity with the reference fixtures, IP-Adapter
+key renumbering, window planning."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def apply_coef(coef, clip, x, eps, noise):
+    x0 = (x - coef[0] * eps) * coef[1]
+    if clip > 0:
+        x0 = x0.clamp(-clip, clip)
+    den = coef[2] * x0 + coef[3] * x
+    prev = coef[4] * den + coef[5] * eps + (coef[6] * noise if noise is not None else 0)
+    return prev, den
+
+
+@pytest.mark.parametrize("name", ["DDIMScheduler", "LCMScheduler", "EulerDiscreteScheduler", "custom_lcm"])
+def test_scheduler_coefficients_equal_oracle_steps(name):
+    from controlanimate_amd import schedulers as P
+    from oracle import schedulers as O
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="linear")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 4, 4, 8, 8, generator=g)
+    n_steps = 6
+    if name == "custom_lcm":
+        p, o = P.LCMScheduler(), O.CustomLCM()
+        p.set_timesteps(0.5, 4, 50)
+        o.set_timesteps(0.5, 4, 50)
+    else:
+        p = P.get_scheduler(name, **kw)
+        o = {"DDIMScheduler": O.DDIM, "LCMScheduler": O.DiffusersLCM, "EulerDiscreteScheduler": O.EulerDiscrete}[name](**kw)
+        p.set_timesteps(n_steps)
+        o.set_timesteps(n_steps)
+    assert torch.equal(torch.as_tensor(p.timesteps).double(), torch.as_tensor(o.timesteps).double())
+    assert abs(float(p.init_noise_sigma) - float(o.init_noise_sigma)) < 1e-5
+    xp = xo = x * float(o.init_noise_sigma)
+    for i, t in enumerate(o.timesteps):
+        eps = torch.randn(x.shape, generator=g)
+        noise = torch.randn(x.shape, generator=g)
+        sc = p.input_scale(i)
+        so = o.scale_model_input(torch.ones(1), t)
+        assert abs(sc - float(so)) < 1e-6
+        coef, clip = p.coefficients(i)
+        xp, _ = apply_coef(coef, clip, xp, eps, noise if p.needs_noise else None)
+        if name == "custom_lcm":
+            xo, _ = o.step(eps, i, t, xo, noise=noise)
+        elif name == "LCMScheduler":
+            xo, _ = o.step(eps, t, xo, noise=noise)
+        else:
+            xo, _ = o.step(eps, t, xo)
+        assert torch.allclose(xp, xo, atol=2e-5, rtol=2e-5), (name, i, (xp - xo).abs().max())
+
+
+def test_lcm_timesteps_known_answers():
+    from controlanimate_amd.schedulers import DiffusersLCMScheduler, LCMScheduler
+    s = LCMScheduler()
+    s.set_timesteps(1.0, 20, 50)
+    assert s.timesteps.tolist() == list(range(999, 238, -40))
+    s.set_timesteps(0.5, 4, 50)
+    assert s.timesteps.tolist() == [499, 379, 259, 139]
+    fx = np.load(os.path.join(G, "lcm_custom.npz"))
+    for k, (strength, steps) in enumerate(fx["combos"]):
+        s.set_timesteps(float(strength), int(steps), 50)
+        assert np.array_equal(s.timesteps.numpy(), fx[f"timesteps_{k}"])
+    assert np.allclose(s.alphas_cumprod.numpy(), fx["alphas_cumprod"], rtol=0, atol=0)
+    d = DiffusersLCMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear")
+    d.set_timesteps(20)
+    assert d.timesteps.tolist() == list(range(999, 238, -40))
+
+
+def test_state_dict_keys_and_processor_order_match_reference():
+    from controlanimate_amd.configs import unet_config
+    from controlanimate_amd.unet import UNet3DConditionModel
+    ref = json.load(open(os.path.join(G, "unet3d_keys.json")))
+    for ver in ("v1", "v2"):
+        with torch.device("meta"):
+            m = UNet3DConditionModel.from_config(unet_config(ver))
+        mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+        # the reference additionally carries 80 never-used block-level to_q/k/v/out tensors
+        theirs = {k: v for k, v in ref[ver]["keys"].items() if ".transformer_blocks.0.to_" not in k}
+        assert mine == theirs
+        assert list(m.attn_processors.keys()) == ref[ver]["attn_processors"]
+        assert len(m.attn_processors) == (88 if ver == "v1" else 90)
+
+
+def test_controlnet_keys_match_oracle_table():
+    from controlanimate_amd.configs import controlnet_config
+    from controlanimate_amd.controlnet import ControlNetModel
+    from oracle.controlnet import ControlNetConfig, controlnet_param_shapes
+    with torch.device("meta"):
+        m = ControlNetModel.from_config(controlnet_config())
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == controlnet_param_shapes(ControlNetConfig())
+    assert sum(int(np.prod(s)) for s in mine.values()) == 361_279_120
+
+
+def test_weight_packing_layouts_on_cpu():
+    from controlanimate_amd.attention import GEGLU
+    from controlanimate_amd.attention_processor import Attention
+    from controlanimate_amd.layers import HipConv3x3, WeightArena, geglu_interleave
+    arena = WeightArena()
+    conv = HipConv3x3(4, 16)
+    conv.pack(arena, torch.float16)
+    geglu = GEGLU(8, 16)
+    geglu.pack(arena, torch.float16)
+    attn = Attention(32, heads=4, dim_head=8)
+    attn.pack(arena, torch.float16)
+    xattn = Attention(32, cross_attention_dim=24, heads=4, dim_head=8)
+    xattn.pack(arena, torch.float16)
+    buf = arena.finalize("cpu")
+    assert buf.dtype == torch.uint8 and all(p.offset % 256 == 0 for p in arena.items)
+    w = conv.w.t.float()
+    assert w.shape == (16, 3, 3, 8)
+    assert torch.equal(w[..., :4], conv.weight.detach().permute(0, 2, 3, 1).half().float()) and w[..., 4:].abs().max() == 0
+    gw = geglu.w.t.float()
+    assert torch.equal(gw[0::2], geglu.proj.weight.detach()[:16].half().float())
+    assert torch.equal(gw[1::2], geglu.proj.weight.detach()[16:].half().float())
+    assert torch.equal(geglu_interleave(torch.arange(6.0)), torch.tensor([0., 3., 1., 4., 2., 5.]))
+    qkv = attn.qkv.t.float()
+    assert torch.equal(qkv[32:64], attn.to_k.weight.detach().half().float())
+    assert xattn.kv.t.shape == (64, 24) and xattn.to_q.w.t.shape == (32, 32)
+
+
+def test_ip_adapter_key_renumbering():
+    from controlanimate_amd.ip_adapter import IPAdapter
+    ref = json.load(open(os.path.join(G, "unet3d_keys.json")))
+    keys = ref["v2"]["attn_processors"]
+    ip_state = {}
+    for n in range(1, 32, 2):                      # SD1.5 ip-adapter checkpoints: layers 1,3,...,31
+        ip_state[f"{n}.to_k_ip.weight"] = torch.tensor([float(n)])
+        ip_state[f"{n}.to_v_ip.weight"] = torch.tensor([float(n) + 0.5])
+    new = IPAdapter.renumber_ip_keys(ip_state, keys)
+    slots = [2, 5, 12, 15, 22, 25, 42, 45, 48, 57, 60, 63, 72, 75, 78, 87]   # SURVEY App. C-7 (verified on the reference)
+    assert [i for i, k in enumerate(keys) if "attn2" in k] == slots
+    assert sorted({int(k.split(".")[0]) for k in new}) == slots
+    for j, s in enumerate(slots):
+        assert float(new[f"{s}.to_k_ip.weight"]) == 2 * j + 1
+    assert keys[slots[-1]].startswith("mid_block")   # order: down, up, then mid
+
+
+def test_window_plan_and_blend():
+    from controlanimate_amd.window_shard import blend_overlap, window_plan, windows_for_rank
+    plan = window_plan(40, 16, 8)
+    assert plan == [(0, 16), (8, 24), (16, 32), (24, 40)]
+    assert window_plan(10, 16, 8) == [(0, 10)]
+    assert window_plan(20, 16, 4) == [(0, 16), (12, 20)]
+    assert windows_for_rank(7, 1, 4) == [1, 5] and sum(len(windows_for_rank(7, r, 4)) for r in range(4)) == 7
+    prev, cur = torch.ones(4, 2, 2), torch.zeros(4, 2, 2)
+    out = blend_overlap(prev, cur)
+    assert torch.allclose(out[:, 0, 0], torch.tensor([3.5, 2.5, 1.5, 0.5]) / 4)  # Image.blend alpha (n-i-0.5)/n
+    with pytest.raises(ValueError):
+        window_plan(10, 8, 8)
