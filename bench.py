@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="also print the per-shape GEMM/conv table (stderr)")
     return ap.parse_args()
 
 
@@ -61,7 +62,8 @@ class KernelTimer:
     kernels are launched on: torch's current stream) + the algorithmic FLOPs of each launch."""
 
     def __init__(self):
-        self.records = []  # (variant, flops, start_event, end_event)
+        self.records = []  # (variant, flops, start_event, end_event, shape)
+        self.other = []
         self.enabled = False
 
     def install(self):
@@ -77,7 +79,7 @@ class KernelTimer:
             out = gemm0(a, w, **kw)
             e.record()
             m, n, k = a.shape[0], w.shape[0], w.shape[1]
-            timer.records.append((f"gemm_{'128x128' if n % 128 == 0 else '128x64'}", 2.0 * m * n * k, s, e))
+            timer.records.append((f"gemm_{'128x128' if n % 128 == 0 else '128x64'}", 2.0 * m * n * k, s, e, (m, n, k)))
             return out
 
         def conv3x3(x, w, **kw):
@@ -89,14 +91,54 @@ class KernelTimer:
             e.record()
             n = w.shape[0]
             mrows = out.shape[0] * out.shape[1] * out.shape[2]
-            timer.records.append((f"conv3x3_{'128x128' if n % 128 == 0 else '128x64'}", 2.0 * mrows * n * 9 * w.shape[3], s, e))
+            timer.records.append((f"conv3x3_{'128x128' if n % 128 == 0 else '128x64'}", 2.0 * mrows * n * 9 * w.shape[3], s, e,
+                                  (mrows, n, 9 * w.shape[3])))
             return out
 
         K.gemm, K.conv3x3 = gemm, conv3x3
 
+        def wrap_other(name, shape_of):
+            fn0 = getattr(K, name)
+
+            def fn(*a, **kw):
+                if not timer.enabled:
+                    return fn0(*a, **kw)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = fn0(*a, **kw)
+                e.record()
+                timer.other.append((name, shape_of(*a, **kw), s, e))
+                return out
+            setattr(K, name, fn)
+
+        wrap_other("attention_raw", lambda q, k, v, o, **kw: (kw["batches"], kw["heads"], kw["head_dim"], kw["nq"], kw["nk"]))
+        wrap_other("group_norm", lambda x, g, b, **kw: tuple(x.shape) + ((kw["x2"].shape[3],) if kw.get("x2") is not None else (0,)))
+        wrap_other("layer_norm", lambda x, g, b, **kw: tuple(x.shape))
+        wrap_other("add_bcast", lambda a, b, out=None: (a.numel(),))
+
+    def other_summary(self, top=30):
+        agg = {}
+        for name, shape, s, e in self.other:
+            d = agg.setdefault((name,) + tuple(shape), dict(n=0, ms=0.0))
+            d["n"] += 1
+            d["ms"] += s.elapsed_time(e)
+        rows = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:top]
+        return [dict(op=k[0], shape=k[1:], launches=v["n"], ms=round(v["ms"], 3), avg_us=round(1e3 * v["ms"] / v["n"], 1)) for k, v in rows]
+
+    def by_shape(self, top=25):
+        agg = {}
+        for name, flops, s, e, shape in self.records:
+            d = agg.setdefault((name.split("_")[0],) + shape, dict(n=0, flops=0.0, ms=0.0))
+            d["n"] += 1
+            d["flops"] += flops
+            d["ms"] += s.elapsed_time(e)
+        rows = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:top]
+        return [dict(op=k[0], m=k[1], n=k[2], k=k[3], launches=v["n"], ms=round(v["ms"], 3), avg_us=round(1e3 * v["ms"] / v["n"], 1),
+                     tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in rows]
+
     def summary(self):
         agg = {}
-        for name, flops, s, e in self.records:
+        for name, flops, s, e, _shape in self.records:
             d = agg.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
@@ -266,6 +308,11 @@ def main():
                                "share_of_step_time": round(d["ms"] * 1e-3 / elapsed, 4)}
             out["kernel_family"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2),
                                         "time_share": round(v["ms"] * 1e-3 / elapsed, 4)} for k, v in sorted(agg.items())}
+    if args.shapes and rank == 0 and not args.no_roofline:
+        for row in timer.by_shape():
+            print(row, file=sys.stderr)
+        for row in timer.other_summary():
+            print(row, file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(usable_cores())
     if rank == 0:

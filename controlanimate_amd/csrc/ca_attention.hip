@@ -12,6 +12,7 @@
 // One kernel serves spatial self-attention, text/IP cross-attention (K/V shared by the frames of
 // a batch element) and temporal attention (strided rows) via the batch/row strides.
 #include "ca_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -29,9 +30,10 @@ struct AttnKParams {
   float scale_log2;
   float out_scale;
   int accumulate;
+  int sum_row;  // 1: V^T row `head_dim` is all ones, so the PV MFMA also produces the softmax row sums
 };
 
-template <int DT, int DK32, int DV16, int QT, int NW, int KB>
+template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool PF>
 __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   constexpr int NT = NW * 64;
   constexpr int DKP = DK32 * 32;
@@ -40,9 +42,12 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   constexpr int VLD = KB + 8;   // V^T tile row stride (elements)
   constexpr int KT = KB / 16;
   constexpr int KC = KB / 32;
-  __shared__ __attribute__((aligned(16))) u16 smem[KB * KLD + DVP * VLD];
-  u16* Ks = smem;
-  u16* Vts = smem + KB * KLD;
+  // PF: the next K/V tile's global loads are issued before the MFMA phase of the current one and
+  // written to the OTHER LDS buffer after it (one barrier per tile, no exposed load latency).
+  constexpr int TILE = KB * KLD + DVP * VLD;
+  constexpr int KI = (KB * (DKP / 8) + NT - 1) / NT;         // K chunks staged per thread
+  constexpr int VI = ((KB / 4) * (DVP / 8) + NT - 1) / NT;   // V key-quads staged per thread
+  __shared__ __attribute__((aligned(16))) u16 smem[(PF ? 2 : 1) * TILE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -88,40 +93,82 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     for (int dt = 0; dt < DV16; ++dt) oacc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int kv0 = 0; kv0 < p.nk; kv0 += KB) {
-    __syncthreads();
-    // ---- stage K tile: [KB keys][DKP] row-major, zero padded ------------------------------
-    for (int it = tid; it < KB * (DKP / 8); it += NT) {
+  u32x4 rk[KI], rv[VI][4];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int u = 0; u < KI; ++u) {
+      const int it = tid + u * NT;
       const int key = it / (DKP / 8), dc = it - key * (DKP / 8);
       const int kg = kv0 + key;
-      u32x4 val = (kg < p.nk && dc * 8 < p.head_dim) ? ld16(kp + (int64_t)kg * p.k_row + dc * 8) : zero4;
-      st16(Ks + key * KLD + dc * 8, val);
+      rk[u] = (it < KB * (DKP / 8) && kg < p.nk && dc * 8 < p.head_dim) ? ld16(kp + (int64_t)kg * p.k_row + dc * 8) : zero4;
     }
-    // ---- stage V^T tile: [DVP dv][KB keys (permuted)] ---------------------------------------
-    for (int it = tid; it < (KB / 4) * (DVP / 8); it += NT) {
+#pragma unroll
+    for (int u = 0; u < VI; ++u) {
+      const int it = tid + u * NT;
       const int quad = it / (DVP / 8), dc = it - quad * (DVP / 8);
-      const int pos = (quad >> 3) * 32 + (quad & 3) * 8 + ((quad >> 2) & 1) * 4;
-      u32x4 r[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kg = kv0 + quad * 4 + j;
-        r[j] = (kg < p.nk && dc * 8 < p.head_dim) ? ld16(vp + (int64_t)kg * p.k_row + dc * 8) : zero4;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int w = i >> 1;
-        u32x2 o;
-        if (i & 1) {
-          o[0] = (r[0][w] >> 16) | (r[1][w] & 0xffff0000u);
-          o[1] = (r[2][w] >> 16) | (r[3][w] & 0xffff0000u);
-        } else {
-          o[0] = (r[0][w] & 0xffffu) | (r[1][w] << 16);
-          o[1] = (r[2][w] & 0xffffu) | (r[3][w] << 16);
-        }
-        *reinterpret_cast<u32x2*>(Vts + (dc * 8 + i) * VLD + pos) = o;
+        rv[u][j] = (it < (KB / 4) * (DVP / 8) && kg < p.nk && dc * 8 < p.head_dim) ? ld16(vp + (int64_t)kg * p.k_row + dc * 8) : zero4;
       }
     }
+  };
+  auto store_tile = [&](int buf) {
+    u16* Ks = smem + buf * TILE;
+    u16* Vts = Ks + KB * KLD;
+    // K tile: [KB keys][DKP] row-major, zero padded
+#pragma unroll
+    for (int u = 0; u < KI; ++u) {
+      const int it = tid + u * NT;
+      if (it < KB * (DKP / 8)) {
+        const int key = it / (DKP / 8), dc = it - key * (DKP / 8);
+        st16(Ks + key * KLD + dc * 8, rk[u]);
+      }
+    }
+    // V^T tile: [DVP dv][KB keys (permuted inside every 32-key chunk)]
+#pragma unroll
+    for (int u = 0; u < VI; ++u) {
+      const int it = tid + u * NT;
+      if (it < (KB / 4) * (DVP / 8)) {
+        const int quad = it / (DVP / 8), dc = it - quad * (DVP / 8);
+        const int pos = (quad >> 3) * 32 + (quad & 3) * 8 + ((quad >> 2) & 1) * 4;
+        const int i_one = p.sum_row ? p.head_dim - dc * 8 : -1;  // the all-ones row, if it falls in this chunk
+        const unsigned ones = DT == CA_F16 ? 0x3C003C00u : 0x3F803F80u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int w = i >> 1;
+          u32x2 o;
+          if (i & 1) {
+            o[0] = (rv[u][0][w] >> 16) | (rv[u][1][w] & 0xffff0000u);
+            o[1] = (rv[u][2][w] >> 16) | (rv[u][3][w] & 0xffff0000u);
+          } else {
+            o[0] = (rv[u][0][w] & 0xffffu) | (rv[u][1][w] << 16);
+            o[1] = (rv[u][2][w] & 0xffffu) | (rv[u][3][w] << 16);
+          }
+          if (i == i_one) o = (u32x2){ones, ones};
+          *reinterpret_cast<u32x2*>(Vts + (dc * 8 + i) * VLD + pos) = o;
+        }
+      }
+    }
+  };
+
+  if (PF) {
+    load_tile(0);
+    store_tile(0);
     __syncthreads();
+    if (KB < p.nk) load_tile(KB);
+  }
+  int iter = 0;
+  for (int kv0 = 0; kv0 < p.nk; kv0 += KB, ++iter) {
+    const int buf = PF ? (iter & 1) : 0;
+    if (!PF) {
+      __syncthreads();
+      load_tile(kv0);
+      store_tile(0);
+      __syncthreads();
+    }
+    const u16* Ks = smem + buf * TILE;
+    const u16* Vts = Ks + KB * KLD;
 
     // ---- S^T = K Q^T ----------------------------------------------------------------------
     f32x4 sacc[QT][KT];
@@ -140,48 +187,54 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     }
 
     // ---- online softmax (per lane = per query column) and P^T fragments ---------------------
+    // VALU budget matters as much as MFMA at head_dim 40: per score one fma + one v_exp + a share
+    // of a max and of a pack; masking only in the tail tile; row sums come out of the PV MFMA via
+    // the all-ones V^T row when there is a spare padded row (sum_row).
     u32x4 pf[QT][KC];
+    const bool tail = kv0 + KB > p.nk;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      float mloc = -INFINITY;
+      if (tail) {
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + kt * 16 + g * 4 + r;
-          float s = key < p.nk ? sacc[t][kt][r] : -INFINITY;
-          sacc[t][kt][r] = s;
-          mloc = fmaxf(mloc, s);
-        }
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + kt * 16 + g * 4 + r >= p.nk) sacc[t][kt][r] = -INFINITY;
       }
+      float mloc = fmaxf(fmaxf(sacc[t][0][0], sacc[t][0][1]), fmaxf(sacc[t][0][2], sacc[t][0][3]));
+#pragma unroll
+      for (int kt = 1; kt < KT; ++kt)
+        mloc = fmaxf(fmaxf(fmaxf(mloc, sacc[t][kt][0]), fmaxf(sacc[t][kt][1], sacc[t][kt][2])), sacc[t][kt][3]);
       mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
       const float mnew = fmaxf(mrun[t], mloc);
-      const float alpha = exp2f((mrun[t] - mnew) * p.scale_log2);
-      float psum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = exp2f((sacc[t][kt][r] - mnew) * p.scale_log2);
-          sacc[t][kt][r] = pv;
-          psum += pv;
-        }
-      }
-      psum += __shfl_xor(psum, 16);
-      psum += __shfl_xor(psum, 32);
-      lrun[t] = lrun[t] * alpha + psum;
+      const float nmc = -mnew * p.scale_log2;
+      const float alpha = __builtin_amdgcn_exp2f(fmaf(mrun[t], p.scale_log2, nmc));
       mrun[t] = mnew;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
+      if (!p.sum_row) {
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) psum += sacc[t][kt][r];
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        lrun[t] = lrun[t] * alpha + psum;
+      }
 #pragma unroll
       for (int dt = 0; dt < DV16; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) oacc[t][dt][r] *= alpha;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
-        pf[t][c][0] = pack2<DT>(sacc[t][2 * c][0], sacc[t][2 * c][1]);
-        pf[t][c][1] = pack2<DT>(sacc[t][2 * c][2], sacc[t][2 * c][3]);
-        pf[t][c][2] = pack2<DT>(sacc[t][2 * c + 1][0], sacc[t][2 * c + 1][1]);
-        pf[t][c][3] = pack2<DT>(sacc[t][2 * c + 1][2], sacc[t][2 * c + 1][3]);
+        pf[t][c][0] = pack2_prob<DT>(sacc[t][2 * c][0], sacc[t][2 * c][1]);
+        pf[t][c][1] = pack2_prob<DT>(sacc[t][2 * c][2], sacc[t][2 * c][3]);
+        pf[t][c][2] = pack2_prob<DT>(sacc[t][2 * c + 1][0], sacc[t][2 * c + 1][1]);
+        pf[t][c][3] = pack2_prob<DT>(sacc[t][2 * c + 1][2], sacc[t][2 * c + 1][3]);
       }
     }
 
@@ -195,14 +248,27 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
         for (int t = 0; t < QT; ++t) oacc[t][dt] = Elem<DT>::mfma(vf, pf[t][c], oacc[t][dt]);
       }
     }
+    if (PF) {
+      if (kv0 + KB < p.nk) store_tile(buf ^ 1);
+      __syncthreads();
+      if (kv0 + 2 * KB < p.nk) load_tile(kv0 + 2 * KB);
+    }
   }
 
   // ---- epilogue: lane holds O[q = .. + l15][dv = dt*16 + 4g + r] ------------------------------
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int qi = q0 + t * 16 + l15;
+    float lsum = lrun[t];
+    if (p.sum_row) {  // row sums live in O^T[head_dim][q]: lanes of group (head_dim % 16) / 4, register 0
+      float lv = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < DV16; ++dt)
+        if (dt == (p.head_dim >> 4)) lv = oacc[t][dt][0];
+      lsum = __shfl(lv, (((p.head_dim & 15) >> 2) << 4) + l15);
+    }
     if (qi >= p.nq) continue;
-    const float inv = p.out_scale / lrun[t];
+    const float inv = p.out_scale / lsum;
     u16* orow = op + (int64_t)qi * p.o_row;
 #pragma unroll
     for (int dt = 0; dt < DV16; ++dt) {
@@ -231,13 +297,17 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
   AttnKParams p = p0;
   if (p.nq <= 16 && p.nk <= 32) {
     p.qblocks = 1;
-    hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 1, 1, 32>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
+    hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 1, 1, 32, false>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
   } else if (p.nq <= 32 && p.nk <= 32) {
     p.qblocks = 1;
-    hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 1, 32>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
+    hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 1, 32, false>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
   } else {
+    // register prefetch of the next K/V tile only where the staging registers fit (head_dim <= 96)
+    static const int pf_env = getenv("CA_ATTN_PF") ? atoi(getenv("CA_ATTN_PF")) : 1;  // tuning knob
     p.qblocks = ceil_div_i(p.nq, 128);
-    hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 4, 64>), dim3((unsigned)(p.qblocks * p.batches * p.heads)), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)(p.qblocks * p.batches * p.heads));
+    if (DK32 <= 3 && pf_env) hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 4, 64, (DK32 <= 3)>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 4, 64, false>), grid, dim3(256), 0, st, p);
   }
 }
 
@@ -286,6 +356,11 @@ extern "C" int ca_attention(const ca_attn_args* a, void* stream) {
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.out_scale = a->out_scale;
   p.accumulate = a->accumulate;
+  {
+    const int d = a->head_dim;
+    const int dvp = d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : d <= 80 ? 80 : d <= 128 ? 128 : 160;
+    p.sum_row = (d < dvp && d % 4 == 0) ? 1 : 0;
+  }
   if (a->dtype == CA_BF16) launch_attn<CA_BF16>(p, (hipStream_t)stream);
   else launch_attn<CA_F16>(p, (hipStream_t)stream);
   CA_CHECK_LAUNCH("ca_attention");

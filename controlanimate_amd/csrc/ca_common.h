@@ -64,6 +64,17 @@ template <int DT>
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   return (unsigned)Elem<DT>::from_f(lo) | ((unsigned)Elem<DT>::from_f(hi) << 16);
 }
+// Packing of softmax probabilities (values in [0,1]): fp16 uses the single-instruction
+// round-toward-zero pack (v_cvt_pkrtz_f16_f32); bf16's v_cvt_pk_bf16_f32 already is one instruction.
+template <int DT>
+__device__ __forceinline__ unsigned pack2_prob(float lo, float hi) {
+  if (DT == CA_F16) {
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    h2 r = __builtin_amdgcn_cvt_pkrtz(lo, hi);
+    return __builtin_bit_cast(unsigned, r);
+  }
+  return pack2<DT>(lo, hi);
+}
 template <int DT>
 __device__ __forceinline__ void unpack8(u32x4 v, float* f) {
 #pragma unroll
@@ -81,7 +92,15 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU; erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below fp16/bf16 output
+// rounding) -- one v_exp + one v_rcp instead of the ~30-instruction libm erff in the GEGLU epilogue.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }

@@ -5,9 +5,16 @@
 //   two-source channel concat).  Both operands are K-contiguous, so MFMA fragments are plain
 //   16-byte reads.
 //
-// Tiling: 256 threads = 4 waves, block tile BM x BN x 64, double-buffered LDS, register-staged
-// global->LDS copies issued one tile ahead (loads in flight during the MFMA phase, written to
-// the other LDS buffer after it: one barrier per K tile).  LDS rows are 128 B (64 elements);
+// Tiling: 256 threads = 4 waves, block tile BM x BN x 64, double-buffered LDS, one barrier per K
+// tile.  Two staging variants share the MFMA loop and the epilogue:
+//   k_gemm_dma  global->LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPR round trip, no
+//               ds_write pass; out-of-range lanes (conv halo, M/N tails) are given an offset beyond
+//               the buffer descriptor's size and the hardware writes zeros (probed on MI355X,
+//               tools/probe_glds.hip).  The DMA writes lane-linear, so the bank swizzle is applied
+//               to the per-lane SOURCE chunk and again on the fragment read (same involution).
+//               Needs channel counts that are multiples of 64 (every UNet/ControlNet layer but conv_in).
+//   k_gemm      register-staged copies issued one tile ahead; handles any multiple-of-8 shape.
+// LDS rows are 128 B (64 elements);
 // the 16-byte chunk index is XOR-swizzled with (row>>1)&7 so that every ds_read_b128 lane group
 // of a fragment read hits 16 distinct 16-B slots (MI355X_MICROARCH.md, LDS table).
 // MFMA is issued with swapped operands (mfma(Wfrag, Afrag)) so each lane ends up holding 4
@@ -25,6 +32,7 @@ struct GemmKParams {
   const float* rowbias;
   const u16* res;
   int64_t lda, lda2, ldc, ld_res, ld_rowbias;
+  unsigned a_bytes, a2_bytes, w_bytes;  // buffer-descriptor sizes for the LDS-DMA variant
   int m, n;
   int c1, c2;      // channels (K per tap) from source 1 / 2
   int taps;        // 1 (dense) or 9 (3x3)
@@ -40,6 +48,165 @@ constexpr int BK = 64;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+// ---- direct epilogue (N < 8 only): lane holds C[m = .. + l15][n = .. + 4g + (0..3)] -----------
+template <int DT, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmKParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                                     int l15, int g) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * TM * 16 + i * 16 + l15;
+    if (m >= p.m) continue;
+    const float* rbp = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 16 + j * 16 + g * 4;
+      if (n >= p.n) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      if (p.bias) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += b[r];
+      }
+      if (rbp) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(rbp + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += b[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+      if (p.res) {
+        u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + (int64_t)m * p.ld_res + n);
+        v[0] += Elem<DT>::to_f((u16)(rr[0] & 0xffffu));
+        v[1] += Elem<DT>::to_f((u16)(rr[0] >> 16));
+        v[2] += Elem<DT>::to_f((u16)(rr[1] & 0xffffu));
+        v[3] += Elem<DT>::to_f((u16)(rr[1] >> 16));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= p.post;
+      if (p.act == CA_ACT_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+      }
+      if (p.geglu) {
+        float o0 = v[0] * gelu_erf_f(v[1]);
+        float o1 = v[2] * gelu_erf_f(v[3]);
+        const int64_t off = (int64_t)m * p.ldc + (n >> 1);
+        if (p.out_f32) {
+          float* cp = reinterpret_cast<float*>(p.c) + off;
+          cp[0] = o0;
+          cp[1] = o1;
+        } else {
+          *reinterpret_cast<unsigned*>(reinterpret_cast<u16*>(p.c) + off) = pack2<DT>(o0, o1);
+        }
+      } else {
+        const int64_t off = (int64_t)m * p.ldc + n;
+        if (p.out_f32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + off) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+          u32x2 o;
+          o[0] = pack2<DT>(v[0], v[1]);
+          o[1] = pack2<DT>(v[2], v[3]);
+          *reinterpret_cast<u32x2*>(reinterpret_cast<u16*>(p.c) + off) = o;
+        }
+      }
+    }
+  }
+}
+
+// ---- LDS-staged epilogue: the accumulator fragments (8-byte pieces scattered over 16 rows per
+// store) are transposed through LDS so that global traffic is 16-byte accesses covering whole
+// 256-byte row segments: coalesced residual reads and output writes.  The K-loop buffers are free
+// at this point (the loop ends with a barrier).  Staged value = (acc + bias + rowbias) * alpha
+// rounded to the activation type; the residual is added in fp32 afterwards (the reference's fp16
+// pipeline rounds at the same place: linear output, then `+ hidden_states`).
+template <int DT, int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)[TM][TN], u16* cs, int m0, int n0, int wm, int wn,
+                                              int l15, int g, int tid) {
+  if (p.n < 8) {  // conv_out (Cout = 4)
+    gemm_epilogue_direct<DT, TM, TN>(p, acc, m0, n0, wm, wn, l15, g);
+    return;
+  }
+  constexpr int CLD = BN + 8;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = wm * TM * 16 + i * 16 + l15;
+    const int m = m0 + row;
+    const float* rbp = (p.rowbias && m < p.m) ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * TN * 16 + j * 16 + g * 4;
+      const int n = n0 + col;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      if (n < p.n) {
+        if (p.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += b[r];
+        }
+        if (rbp) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(rbp + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += b[r];
+        }
+      }
+      u32x2 o;
+      o[0] = pack2<DT>(v[0] * p.alpha, v[1] * p.alpha);
+      o[1] = pack2<DT>(v[2] * p.alpha, v[3] * p.alpha);
+      *reinterpret_cast<u32x2*>(cs + row * CLD + col) = o;
+    }
+  }
+  __syncthreads();
+  constexpr int CH = BN / 8;
+#pragma unroll
+  for (int u = 0; u < BM * CH / 256; ++u) {
+    const int id = tid + u * 256;
+    const int row = id / CH, c8 = id - row * CH;
+    const int m = m0 + row, n = n0 + c8 * 8;
+    if (m >= p.m || n >= p.n) continue;
+    float v[8];
+    unpack8<DT>(ld16(cs + row * CLD + c8 * 8), v);
+    if (p.res) {
+      float r[8];
+      unpack8<DT>(ld16(p.res + (int64_t)m * p.ld_res + n), r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += r[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= p.post;
+    if (p.act == CA_ACT_SILU) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = silu_f(v[k]);
+    }
+    if (p.geglu) {
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = v[2 * k] * gelu_erf_f(v[2 * k + 1]);
+      const int64_t off = (int64_t)m * p.ldc + (n >> 1);
+      if (p.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + off) = (f32x4){o[0], o[1], o[2], o[3]};
+      } else {
+        u32x2 w;
+        w[0] = pack2<DT>(o[0], o[1]);
+        w[1] = pack2<DT>(o[2], o[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<u16*>(p.c) + off) = w;
+      }
+    } else {
+      const int64_t off = (int64_t)m * p.ldc + n;
+      if (p.out_f32) {
+        float* cp = reinterpret_cast<float*>(p.c) + off;
+        *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      } else {
+        st16(reinterpret_cast<u16*>(p.c) + off, pack8<DT>(v));
+      }
+    }
+  }
 }
 
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
@@ -175,81 +342,164 @@ __global__ __launch_bounds__(256) void k_gemm(GemmKParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds C[m = .. + l15][n = .. + 4g + (0..3)] -----------------------
+  gemm_epilogue<DT, BM, BN, TM, TN>(p, acc, smem, m0, n0, wm, wn, l15, g, tid);
+}
+
+// ---- LDS-DMA variant ------------------------------------------------------------------------
+constexpr unsigned DMA_OOB = 0xFFFFFFF0u;  // beyond any descriptor size we accept -> hardware writes zeros
+
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+__global__ __launch_bounds__(256) void k_gemm_dma(GemmKParams p) {
+  constexpr int TM = BM / WAVES_M / 16;
+  constexpr int TN = BN / WAVES_N / 16;
+  constexpr int AG = BM / 32;  // 8-row groups staged per wave (A)
+  constexpr int BG = BN / 32;  // (W)
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * BK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int tiles_n = (p.n + BN - 1) / BN;
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, p.a2 ? p.a2_bytes : p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  const int r8 = lane >> 3, cp = lane & 7;  // row inside an 8-row group, LDS chunk position
+  const int kc = p.c1 + p.c2;
+  const unsigned wld = (unsigned)(p.taps * kc);
+
+  // per staged row: swizzled source chunk, and either a byte offset (dense / weights) or pixel coords (conv)
+  int a_chunk[AG], a_img[AG], a_ho[AG], a_wo[AG];
+  unsigned a_off1[AG], a_off2[AG];
+  bool a_ok[AG];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * TM * 16 + i * 16 + l15;
-    if (m >= p.m) continue;
-    const float* rbp = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias : nullptr;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * TN * 16 + j * 16 + g * 4;
-      if (n >= p.n) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-      if (p.bias) {
-        f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += b[r];
-      }
-      if (rbp) {
-        f32x4 b = *reinterpret_cast<const f32x4*>(rbp + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += b[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-      if (p.res) {
-        u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + (int64_t)m * p.ld_res + n);
-        v[0] += Elem<DT>::to_f((u16)(rr[0] & 0xffffu));
-        v[1] += Elem<DT>::to_f((u16)(rr[0] >> 16));
-        v[2] += Elem<DT>::to_f((u16)(rr[1] & 0xffffu));
-        v[3] += Elem<DT>::to_f((u16)(rr[1] >> 16));
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= p.post;
-      if (p.act == CA_ACT_SILU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-      }
-      if (p.geglu) {
-        float o0 = v[0] * gelu_erf_f(v[1]);
-        float o1 = v[2] * gelu_erf_f(v[3]);
-        const int64_t off = (int64_t)m * p.ldc + (n >> 1);
-        if (p.out_f32) {
-          float* cp = reinterpret_cast<float*>(p.c) + off;
-          cp[0] = o0;
-          cp[1] = o1;
-        } else {
-          *reinterpret_cast<unsigned*>(reinterpret_cast<u16*>(p.c) + off) = pack2<DT>(o0, o1);
-        }
-      } else {
-        const int64_t off = (int64_t)m * p.ldc + n;
-        if (p.out_f32) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + off) = (f32x4){v[0], v[1], v[2], v[3]};
-        } else {
-          u32x2 o;
-          o[0] = pack2<DT>(v[0], v[1]);
-          o[1] = pack2<DT>(v[2], v[3]);
-          *reinterpret_cast<u32x2*>(reinterpret_cast<u16*>(p.c) + off) = o;
-        }
-      }
+  for (int i = 0; i < AG; ++i) {
+    const int row = (wid * AG + i) * 8 + r8;
+    a_chunk[i] = cp ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    a_ok[i] = m < p.m;
+    const int mm = a_ok[i] ? m : p.m - 1;
+    if (MODE == 1) {
+      const int hw = p.hout * p.wout;
+      a_img[i] = mm / hw;
+      const int rem = mm - a_img[i] * hw;
+      a_ho[i] = rem / p.wout;
+      a_wo[i] = rem - a_ho[i] * p.wout;
+      a_off1[i] = a_off2[i] = 0;
+    } else {
+      a_img[i] = a_ho[i] = a_wo[i] = 0;
+      a_off1[i] = (unsigned)((int64_t)mm * p.lda * 2);
+      a_off2[i] = (unsigned)((int64_t)mm * p.lda2 * 2);
     }
   }
+  int b_chunk[BG];
+  unsigned b_off[BG];
+#pragma unroll
+  for (int j = 0; j < BG; ++j) {
+    const int row = (wid * BG + j) * 8 + r8;
+    b_chunk[j] = cp ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    if (n >= p.n) n = p.n - 1;  // clamped rows feed accumulators that are never stored
+    b_off[j] = (unsigned)n * wld * 2u;
+  }
+
+  auto stage = [&](int t, int buf) {
+    u16* sa = smem + buf * (BM + BN) * BK;
+    u16* sb = sa + BM * BK;
+    const int tap = (p.taps == 1) ? 0 : t / p.kc_tiles;
+    const int cc = t - tap * p.kc_tiles;
+    const int c0 = cc * BK;            // first channel of this K tile (tile-uniform)
+    const bool src2 = c0 >= p.c1;      // c1 % 64 == 0 => a tile never straddles the two sources
+    const int cs = src2 ? p.c2 : p.c1;
+    const int cbase = src2 ? c0 - p.c1 : c0;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+      const unsigned off = b_off[j] + (unsigned)(tap * kc + c0 + b_chunk[j] * 8) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(sb + (wid * BG + j) * 8 * BK), 16, off, 0, 0, 0);
+    }
+    if (MODE == 1) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+      for (int i = 0; i < AG; ++i) {
+        const int hi = a_ho[i] * p.stride + kh - 1;
+        const int wi = a_wo[i] * p.stride + kw - 1;
+        const bool ok = a_ok[i] && hi >= 0 && wi >= 0 && hi < (p.hin << p.ups) && wi < (p.win << p.ups);
+        const int pix = (a_img[i] * p.hin + (hi >> p.ups)) * p.win + (wi >> p.ups);
+        const unsigned off = ok ? ((unsigned)pix * (unsigned)cs + (unsigned)(cbase + a_chunk[i] * 8)) * 2u : DMA_OOB;
+        void* dst = sa + (wid * AG + i) * 8 * BK;
+        if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AG; ++i) {
+        const unsigned off = (src2 ? a_off2[i] : a_off1[i]) + (unsigned)(cbase + a_chunk[i] * 8) * 2u;
+        void* dst = sa + (wid * AG + i) * 8 * BK;
+        if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.taps * p.kc_tiles;
+  stage(0, 0);
+  __syncthreads();  // hipcc drains the LDS-DMA queue (vmcnt(0)) ahead of the barrier
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    const u16* sa = smem + buf * (BM + BN) * BK;
+    const u16* sb = sa + BM * BK;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = ld16(sa + lds_off(wm * TM * 16 + i * 16 + l15, s * 4 + g));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = ld16(sb + lds_off(wn * TN * 16 + j * 16 + l15, s * 4 + g));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Elem<DT>::mfma(fb[j], fa[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<DT, BM, BN, TM, TN>(p, acc, smem, m0, n0, wm, wn, l15, g, tid);
 }
 
 template <int DT, int MODE>
 int launch_gemm(const GemmKParams& p, hipStream_t st) {
   // N multiple of 128 -> 128x128 tile; otherwise 128x64 (exact for 320 / 960 wide outputs).
+  const int kc = p.c1 + p.c2;
+  const bool dma = kc % BK == 0 && (p.c2 == 0 || p.c1 % BK == 0) && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0);
   if (p.n % 128 == 0) {
     int tiles = ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128);
-    hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
+    if (dma) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
   } else {
     int tiles = ceil_div_i(p.m, 128) * ceil_div_i(p.n, 64);
-    hipLaunchKernelGGL((k_gemm<DT, 128, 64, 4, 1, MODE>), dim3(tiles), dim3(256), 0, st, p);
+    if (dma) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE>), dim3(tiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm<DT, 128, 64, 4, 1, MODE>), dim3(tiles), dim3(256), 0, st, p);
   }
   return CA_OK;
+}
+
+// descriptor size in bytes, or 0 when the buffer is too large for 32-bit offsets (-> register variant)
+inline unsigned desc_bytes(int64_t elems) {
+  const int64_t b = elems * 2;
+  return (b > 0 && b < (int64_t)0xFFFFFF00ll) ? (unsigned)b : 0u;
 }
 
 int check_epilogue(const char* who, int n, int geglu, int out_f32, int64_t ldc, int64_t ld_res, const void* res) {
@@ -287,6 +537,9 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   p.ldc = a->ldc;
   p.ld_res = a->ld_res;
   p.ld_rowbias = a->ld_rowbias;
+  p.a_bytes = desc_bytes((int64_t)(a->m - 1) * a->lda + a->k1);
+  p.a2_bytes = a->k2 ? desc_bytes((int64_t)(a->m - 1) * a->lda2 + a->k2) : 0u;
+  p.w_bytes = desc_bytes((int64_t)a->n * (a->k1 + a->k2));
   p.m = a->m;
   p.n = a->n;
   p.c1 = a->k1;
@@ -335,6 +588,9 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
   p.ldc = a->cout;
   p.ld_res = a->ld_res;
   p.ld_rowbias = a->ld_rowbias;
+  p.a_bytes = desc_bytes((int64_t)a->images * a->hin * a->win * a->cin1);
+  p.a2_bytes = a->cin2 ? desc_bytes((int64_t)a->images * a->hin * a->win * a->cin2) : 0u;
+  p.w_bytes = desc_bytes((int64_t)a->cout * 9 * (a->cin1 + a->cin2));
   p.m = (int)m64;
   p.n = a->cout;
   p.c1 = a->cin1;

@@ -144,7 +144,7 @@ def test_fullwidth_modules_head_dims_40_80_160(dtype):
     def back(y, b, c, f):
         return K.nhwc_to_ncfhw_f32(y, b, c, f)
 
-    tol = 6e-3 if dtype == torch.bfloat16 else 1.5e-3
+    tol = 8e-3 if dtype == torch.bfloat16 else 1.5e-3
     # ---- resnet 320 -> 640 with shortcut; per-frame and cross-frame GroupNorm
     w = weights("down_blocks.1.resnets.0", int(fx["resnet_seed"]))
     x5, temb = T(fx["resnet_x"]), T(fx["resnet_temb"])
