@@ -57,6 +57,13 @@ def randomize_zero_init_(model, std=0.02, seed=0):
             p.data.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
 
 
+def tile_name(m: int, n: int) -> str:
+    """Mirrors launch_gemm() in csrc/ca_gemm.hip: 128x128 block tile unless N % 128 != 0 or the grid
+    would have fewer than 512 blocks."""
+    wide = n % 128 == 0 and ((m + 127) // 128) * ((n + 127) // 128) >= 512
+    return "128x128" if wide else "128x64"
+
+
 class KernelTimer:
     """HIP-event timing of every ca_gemm / ca_conv3x3 launch (events are recorded on the stream the
     kernels are launched on: torch's current stream) + the algorithmic FLOPs of each launch."""
@@ -79,7 +86,7 @@ class KernelTimer:
             out = gemm0(a, w, **kw)
             e.record()
             m, n, k = a.shape[0], w.shape[0], w.shape[1]
-            timer.records.append((f"gemm_{'128x128' if n % 128 == 0 else '128x64'}", 2.0 * m * n * k, s, e, (m, n, k)))
+            timer.records.append((f"gemm_{tile_name(m, n)}", 2.0 * m * n * k, s, e, (m, n, k)))
             return out
 
         def conv3x3(x, w, **kw):
@@ -91,7 +98,7 @@ class KernelTimer:
             e.record()
             n = w.shape[0]
             mrows = out.shape[0] * out.shape[1] * out.shape[2]
-            timer.records.append((f"conv3x3_{'128x128' if n % 128 == 0 else '128x64'}", 2.0 * mrows * n * 9 * w.shape[3], s, e,
+            timer.records.append((f"conv3x3_{tile_name(mrows, n)}", 2.0 * mrows * n * 9 * w.shape[3], s, e,
                                   (mrows, n, 9 * w.shape[3])))
             return out
 

@@ -130,6 +130,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     for (int u = 0; u < VI; ++u) {
       const int it = tid + u * NT;
       if (it < (KB / 4) * (DVP / 8)) {
+        // (a quad-major lane order would make these 8-byte writes bank-conflict-free, but it scatters
+        // the global loads over 64 rows per instruction and measured slower: 1.71 vs 1.61 ms)
         const int quad = it / (DVP / 8), dc = it - quad * (DVP / 8);
         const int pos = (quad >> 3) * 32 + (quad & 3) * 8 + ((quad >> 2) & 1) * 4;
         const int i_one = p.sum_row ? p.head_dim - dc * 8 : -1;  // the all-ones row, if it falls in this chunk
@@ -306,7 +308,19 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
     static const int pf_env = getenv("CA_ATTN_PF") ? atoi(getenv("CA_ATTN_PF")) : 1;  // tuning knob
     p.qblocks = ceil_div_i(p.nq, 128);
     const dim3 grid((unsigned)(p.qblocks * p.batches * p.heads));
-    if (DK32 <= 3 && pf_env) hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 4, 64, (DK32 <= 3)>), grid, dim3(256), 0, st, p);
+    static const int var_env = getenv("CA_ATTN_VAR") ? atoi(getenv("CA_ATTN_VAR")) : 0;  // experiments (d <= 48 only)
+    if (DK32 == 2 && DV16 == 3 && var_env == 1) {  // KB = 128
+      hipLaunchKernelGGL((k_attn<DT, 2, 3, 2, 4, 128, true>), grid, dim3(256), 0, st, p);
+    } else if (DK32 == 2 && DV16 == 3 && var_env == 2) {  // 8 waves, 256 queries per block
+      p.qblocks = ceil_div_i(p.nq, 256);
+      hipLaunchKernelGGL((k_attn<DT, 2, 3, 2, 8, 64, true>), dim3((unsigned)(p.qblocks * p.batches * p.heads)), dim3(512), 0, st, p);
+    } else if (DK32 == 2 && DV16 == 3 && var_env == 3) {  // 1 q-tile per wave, 64 queries per block
+      p.qblocks = ceil_div_i(p.nq, 64);
+      hipLaunchKernelGGL((k_attn<DT, 2, 3, 1, 4, 64, true>), dim3((unsigned)(p.qblocks * p.batches * p.heads)), dim3(256), 0, st, p);
+    } else if (DK32 == 2 && DV16 == 3 && var_env == 4) {  // 8 waves + KB 128
+      p.qblocks = ceil_div_i(p.nq, 256);
+      hipLaunchKernelGGL((k_attn<DT, 2, 3, 2, 8, 128, true>), dim3((unsigned)(p.qblocks * p.batches * p.heads)), dim3(512), 0, st, p);
+    } else if (DK32 <= 3 && pf_env) hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 4, 64, (DK32 <= 3)>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 4, 64, false>), grid, dim3(256), 0, st, p);
   }
 }

@@ -20,6 +20,7 @@
 // MFMA is issued with swapped operands (mfma(Wfrag, Afrag)) so each lane ends up holding 4
 // consecutive output columns of one output row -> 8-byte epilogue stores.
 #include "ca_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -348,13 +349,19 @@ __global__ __launch_bounds__(256) void k_gemm(GemmKParams p) {
 // ---- LDS-DMA variant ------------------------------------------------------------------------
 constexpr unsigned DMA_OOB = 0xFFFFFFF0u;  // beyond any descriptor size we accept -> hardware writes zeros
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+// NBUF = 2: tile t+1 is issued before the MFMA phase of tile t, `__syncthreads()` (which hipcc
+//           precedes with vmcnt(0)) once per tile.
+// NBUF = 3: tiles are issued TWO ahead into a 3-slot ring; a wave waits with a COUNTED
+//           `s_waitcnt vmcnt(per-tile DMA count)` (tile t landed, tile t+1 may still be in flight),
+//           then a raw s_barrier: DMA transfers stay in flight across barriers
+//           (cdna_hip_programming.md "Pipelining across barriers").  All LDS is one array.
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF>
 __global__ __launch_bounds__(256) void k_gemm_dma(GemmKParams p) {
   constexpr int TM = BM / WAVES_M / 16;
   constexpr int TN = BN / WAVES_N / 16;
   constexpr int AG = BM / 32;  // 8-row groups staged per wave (A)
   constexpr int BG = BN / 32;  // (W)
-  __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) u16 smem[NBUF * (BM + BN) * BK];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -455,11 +462,7 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmKParams p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nt = p.taps * p.kc_tiles;
-  stage(0, 0);
-  __syncthreads();  // hipcc drains the LDS-DMA queue (vmcnt(0)) ahead of the barrier
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) stage(t + 1, buf ^ 1);
+  auto compute = [&](int buf) {
     const u16* sa = smem + buf * (BM + BN) * BK;
     const u16* sb = sa + BM * BK;
 #pragma unroll
@@ -474,24 +477,67 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmKParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = Elem<DT>::mfma(fb[j], fa[i], acc[i][j]);
     }
-    __syncthreads();
+  };
+  if (NBUF == 2) {
+    stage(0, 0);
+    __syncthreads();  // hipcc drains the LDS-DMA queue (vmcnt(0)) ahead of the barrier
+    for (int t = 0; t < nt; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < nt) stage(t + 1, buf ^ 1);
+      compute(buf);
+      __syncthreads();
+    }
+  } else {
+    // NBUF-slot ring, tiles issued NBUF-1 ahead.  Before computing tile t a wave waits until at most
+    // the transfers of the (up to NBUF-2) younger tiles are outstanding, then a raw barrier.
+    constexpr int PER_TILE = AG + BG;  // LDS-DMA instructions per wave per tile
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+      if (i < nt) stage(i, i);
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+      const int younger = nt - 1 - t < NBUF - 2 ? nt - 1 - t : NBUF - 2;
+      if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER_TILE) : "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; tile t-1 is no longer read
+      if (t + NBUF - 1 < nt) stage(t + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
+      compute(buf);
+      buf = buf == NBUF - 1 ? 0 : buf + 1;
+    }
+    __builtin_amdgcn_s_barrier();  // all fragment reads done before the epilogue reuses the LDS
   }
   gemm_epilogue<DT, BM, BN, TM, TN>(p, acc, smem, m0, n0, wm, wn, l15, g, tid);
 }
 
 template <int DT, int MODE>
 int launch_gemm(const GemmKParams& p, hipStream_t st) {
-  // N multiple of 128 -> 128x128 tile; otherwise 128x64 (exact for 320 / 960 wide outputs).
   const int kc = p.c1 + p.c2;
   const bool dma = kc % BK == 0 && (p.c2 == 0 || p.c1 % BK == 0) && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0);
-  if (p.n % 128 == 0) {
-    int tiles = ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128);
-    if (dma) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
+  // tuning knobs (experiments): LDS stages of the DMA pipeline, forced tile width
+  static const int nbuf_env = getenv("CA_GEMM_NBUF") ? atoi(getenv("CA_GEMM_NBUF")) : 0;
+  static const int bn_env = getenv("CA_GEMM_BN") ? atoi(getenv("CA_GEMM_BN")) : 0;
+  const int nt = p.taps * p.kc_tiles;
+  int nbuf = nbuf_env ? nbuf_env : 2;
+  if (nt < nbuf) nbuf = 2;
+  // 128x128 tiles unless N is not a multiple of 128 or the grid would leave CUs idle
+  // (8x8 / 16x16 latent levels: M = 2048 / 8192 rows -> < 2 blocks per CU with the big tile).
+  bool wide = p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128) >= 512;
+  if (bn_env == 64) wide = false;
+  if (bn_env == 128 && p.n % 128 == 0) wide = true;
+  if (wide) {
+    const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128));
+    if (!dma) hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, st, p);
+    else if (nbuf == 3) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 3>), grid, dim3(256), 0, st, p);
+    else if (nbuf == 4) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 2>), grid, dim3(256), 0, st, p);
   } else {
-    int tiles = ceil_div_i(p.m, 128) * ceil_div_i(p.n, 64);
-    if (dma) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE>), dim3(tiles), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm<DT, 128, 64, 4, 1, MODE>), dim3(tiles), dim3(256), 0, st, p);
+    const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 64));
+    if (!dma) hipLaunchKernelGGL((k_gemm<DT, 128, 64, 4, 1, MODE>), grid, dim3(256), 0, st, p);
+    else if (nbuf == 3) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 3>), grid, dim3(256), 0, st, p);
+    else if (nbuf == 4) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 2>), grid, dim3(256), 0, st, p);
   }
   return CA_OK;
 }

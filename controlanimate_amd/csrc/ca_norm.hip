@@ -7,8 +7,11 @@ namespace {
 constexpr int GN_MAX_SLOTS = 5;  // 64 lanes * 8 channels * 5 = 2560 channels
 constexpr int GN_MAX_C = 64 * 8 * GN_MAX_SLOTS;
 
+// Row chunks per statistics group: ~64 rows per block for big images, down to 4 rows per block for
+// the 8x8 / 16x16 latent levels (otherwise a [32, 8, 8, 1280] tensor would run on 32 blocks).
 inline int gn_chunks_host(int64_t rows_per_stat) {
   int64_t n = (rows_per_stat + 63) / 64;
+  if (n < 16) n = (rows_per_stat + 3) / 4 < 16 ? (rows_per_stat + 3) / 4 : 16;
   if (n < 1) n = 1;
   if (n > 256) n = 256;
   return (int)n;

@@ -65,6 +65,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu(capi):
     assert rc == -1 and b"ca_gemm" in lib.ca_last_error()
     assert lib.ca_groupnorm_partials_floats(32, 4096, 1, 32) == 32 * 64 * 32 * 2
     assert lib.ca_groupnorm_partials_floats(2, 4096, 2, 32) == 1 * 128 * 32 * 2
+    assert lib.ca_groupnorm_partials_floats(32, 64, 1, 32) == 32 * 16 * 32 * 2  # small images: 4 rows per chunk
 
 
 def test_no_cpu_fallback_when_library_missing(monkeypatch):
