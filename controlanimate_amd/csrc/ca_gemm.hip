@@ -356,7 +356,7 @@ constexpr unsigned DMA_OOB = 0xFFFFFFF0u;  // beyond any descriptor size we acce
 //           then a raw s_barrier: DMA transfers stay in flight across barriers
 //           (cdna_hip_programming.md "Pipelining across barriers").  All LDS is one array.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF>
-__global__ __launch_bounds__(256) void k_gemm_dma(GemmKParams p) {
+__global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void k_gemm_dma(GemmKParams p) {
   constexpr int TM = BM / WAVES_M / 16;
   constexpr int TN = BN / WAVES_N / 16;
   constexpr int AG = BM / 32;  // 8-row groups staged per wave (A)
@@ -478,7 +478,16 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmKParams p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = Elem<DT>::mfma(fb[j], fa[i], acc[i][j]);
     }
   };
-  if (NBUF == 2) {
+  if (NBUF == 1) {
+    // single LDS buffer (32 KB for 128x128): two barriers per tile, but 3 blocks per CU -- the
+    // other resident blocks' MFMA phases cover this block's transfer latency
+    for (int t = 0; t < nt; ++t) {
+      stage(t, 0);
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  } else if (NBUF == 2) {
     stage(0, 0);
     __syncthreads();  // hipcc drains the LDS-DMA queue (vmcnt(0)) ahead of the barrier
     for (int t = 0; t < nt; ++t) {
@@ -519,22 +528,30 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   static const int nbuf_env = getenv("CA_GEMM_NBUF") ? atoi(getenv("CA_GEMM_NBUF")) : 0;
   static const int bn_env = getenv("CA_GEMM_BN") ? atoi(getenv("CA_GEMM_BN")) : 0;
   const int nt = p.taps * p.kc_tiles;
-  int nbuf = nbuf_env ? nbuf_env : 2;
-  if (nt < nbuf) nbuf = 2;
   // 128x128 tiles unless N is not a multiple of 128 or the grid would leave CUs idle
   // (8x8 / 16x16 latent levels: M = 2048 / 8192 rows -> < 2 blocks per CU with the big tile).
   bool wide = p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128) >= 512;
   if (bn_env == 64) wide = false;
   if (bn_env == 128 && p.n % 128 == 0) wide = true;
+  const int64_t blocks = (int64_t)ceil_div_i(p.m, 128) * ceil_div_i(p.n, wide ? 128 : 64);
+  // LDS stages: ONE buffer (32 KB, two barriers per tile) lets 4 blocks share a CU, whose MFMA phases
+  // cover each other's transfer latency: measured +10..25% over double buffering (2 blocks per CU)
+  // and far better than 3-4 stage rings (1 block per CU).  Small grids (< 2 blocks per CU) have no
+  // co-resident blocks to overlap with and keep the double buffer.
+  int nbuf = nbuf_env ? nbuf_env : (blocks >= 512 ? 1 : 2);
+  if (nbuf < 1 || nbuf > 4) nbuf = 2;
+  if (nbuf > 2 && nt < nbuf) nbuf = 2;
   if (wide) {
     const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128));
     if (!dma) hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, st, p);
+    else if (nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
     else if (nbuf == 3) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 3>), grid, dim3(256), 0, st, p);
     else if (nbuf == 4) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 4>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 2>), grid, dim3(256), 0, st, p);
   } else {
     const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 64));
     if (!dma) hipLaunchKernelGGL((k_gemm<DT, 128, 64, 4, 1, MODE>), grid, dim3(256), 0, st, p);
+    else if (nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 1>), grid, dim3(256), 0, st, p);
     else if (nbuf == 3) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 3>), grid, dim3(256), 0, st, p);
     else if (nbuf == 4) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 4>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 2>), grid, dim3(256), 0, st, p);
