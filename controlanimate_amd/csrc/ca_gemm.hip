@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmKParams p) {
   constexpr int TN = BN / WAVES_N / 16;
   constexpr int AI = BM / 32;  // A rows per loader thread
   constexpr int BI = BN / 32;
+  static_assert(2 * (BM + BN) * BK >= BM * (BN + 8), "epilogue staging must fit");
   __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * BK];
 
   const int tid = threadIdx.x;
@@ -361,7 +362,9 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void k_gemm_dma(GemmKPara
   constexpr int TN = BN / WAVES_N / 16;
   constexpr int AG = BM / 32;  // 8-row groups staged per wave (A)
   constexpr int BG = BN / 32;  // (W)
-  __shared__ __attribute__((aligned(16))) u16 smem[NBUF * (BM + BN) * BK];
+  // the LDS-staged epilogue needs BM x (BN + 8) elements: more than ONE 128x128x64 stage
+  constexpr int SMEM_ELEMS = NBUF * (BM + BN) * BK > BM * (BN + 8) ? NBUF * (BM + BN) * BK : BM * (BN + 8);
+  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_ELEMS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;

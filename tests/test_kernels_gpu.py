@@ -54,6 +54,12 @@ GEMM_CASES = [
     (4096, 1280, 1280, 0, True, False, True, 1.0, 1.0, 0, False, False),
     (1000, 8, 64, 0, True, False, False, 1.0, 1.0, 0, False, False),
     (77, 4, 32, 0, False, False, False, 1.0, 1.0, 0, False, True),
+    # grids of >= 512 blocks take the single-LDS-buffer / 4-blocks-per-CU pipeline
+    (16384, 320, 320, 0, True, False, True, 1.0, 1.0, 0, False, False),
+    (16384, 2560, 320, 0, True, False, False, 1.0, 1.0, 0, True, False),
+    (16384, 960, 320, 0, False, False, False, 1.0, 1.0, 0, False, False),
+    (16384, 1280, 1280, 0, True, True, True, 1.0, 1.0, 0, False, False),
+    (65536, 320, 640, 640, True, False, False, 1.0, 1.0, 0, False, False),
 ]
 
 
@@ -143,6 +149,11 @@ CONV_CASES = [
     (2, 16, 16, 96, 0, 256, 2, False, True, False, False, 1, False),
     (2, 8, 8, 1280, 1280, 1280, 1, False, True, True, False, 0, False),
     (8, 32, 32, 320, 0, 320, 1, False, True, True, True, 0, False),
+    # >= 512 blocks: single-LDS-buffer pipeline
+    (16, 64, 64, 320, 0, 320, 1, False, True, True, True, 0, False),
+    (16, 32, 32, 640, 320, 640, 1, False, True, False, False, 0, False),
+    (16, 32, 32, 640, 0, 640, 1, True, True, False, False, 0, False),
+    (16, 64, 64, 320, 0, 320, 2, False, True, False, False, 0, False),
 ]
 
 
