@@ -16,6 +16,11 @@
 
 namespace {
 
+template <bool B>
+struct BoolC {
+  static constexpr bool value = B;
+};
+
 struct AttnKParams {
   const u16* q;
   const u16* k;
@@ -93,24 +98,43 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     for (int dt = 0; dt < DV16; ++dt) oacc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+  // Per-thread staging assignments are loop-invariant: source pointers, validity and LDS offsets are
+  // computed once; per tile only `kv0 * k_row` is added (the softmax leaves little VALU headroom).
   u32x4 rk[KI], rv[VI][4];
-  auto load_tile = [&](int kv0) {
+  const u16* ksrc[KI];
+  const u16* vsrc[VI];
+  int kkey[KI], klds[KI], vkey[VI], vlds[VI], vone[VI];
+  bool kok[KI], vok[VI], vitem[VI], kitem[KI];
 #pragma unroll
-    for (int u = 0; u < KI; ++u) {
-      const int it = tid + u * NT;
-      const int key = it / (DKP / 8), dc = it - key * (DKP / 8);
-      const int kg = kv0 + key;
-      rk[u] = (it < KB * (DKP / 8) && kg < p.nk && dc * 8 < p.head_dim) ? ld16(kp + (int64_t)kg * p.k_row + dc * 8) : zero4;
-    }
+  for (int u = 0; u < KI; ++u) {
+    const int it = tid + u * NT;
+    const int key = it / (DKP / 8), dc = it - key * (DKP / 8);
+    kitem[u] = it < KB * (DKP / 8);
+    kok[u] = kitem[u] && dc * 8 < p.head_dim;
+    kkey[u] = key;
+    klds[u] = key * KLD + dc * 8;
+    ksrc[u] = kp + (int64_t)key * p.k_row + dc * 8;
+  }
+#pragma unroll
+  for (int u = 0; u < VI; ++u) {
+    const int it = tid + u * NT;
+    const int quad = it / (DVP / 8), dc = it - quad * (DVP / 8);
+    vitem[u] = it < (KB / 4) * (DVP / 8);
+    vok[u] = vitem[u] && dc * 8 < p.head_dim;
+    vkey[u] = quad * 4;
+    vlds[u] = dc * 8 * VLD + (quad >> 3) * 32 + (quad & 3) * 8 + ((quad >> 2) & 1) * 4;
+    vone[u] = p.sum_row ? p.head_dim - dc * 8 : -1;  // the all-ones row, if it falls in this chunk
+    vsrc[u] = vp + (int64_t)quad * 4 * p.k_row + dc * 8;
+  }
+  auto load_tile = [&](int kv0) {
+    const int64_t adv = (int64_t)kv0 * p.k_row;
+#pragma unroll
+    for (int u = 0; u < KI; ++u) rk[u] = (kok[u] && kv0 + kkey[u] < p.nk) ? ld16(ksrc[u] + adv) : zero4;
 #pragma unroll
     for (int u = 0; u < VI; ++u) {
-      const int it = tid + u * NT;
-      const int quad = it / (DVP / 8), dc = it - quad * (DVP / 8);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kg = kv0 + quad * 4 + j;
-        rv[u][j] = (it < (KB / 4) * (DVP / 8) && kg < p.nk && dc * 8 < p.head_dim) ? ld16(vp + (int64_t)kg * p.k_row + dc * 8) : zero4;
-      }
+      for (int j = 0; j < 4; ++j)
+        rv[u][j] = (vok[u] && kv0 + vkey[u] + j < p.nk) ? ld16(vsrc[u] + adv + (int64_t)j * p.k_row) : zero4;
     }
   };
   auto store_tile = [&](int buf) {
@@ -118,24 +142,15 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     u16* Vts = Ks + KB * KLD;
     // K tile: [KB keys][DKP] row-major, zero padded
 #pragma unroll
-    for (int u = 0; u < KI; ++u) {
-      const int it = tid + u * NT;
-      if (it < KB * (DKP / 8)) {
-        const int key = it / (DKP / 8), dc = it - key * (DKP / 8);
-        st16(Ks + key * KLD + dc * 8, rk[u]);
-      }
-    }
+    for (int u = 0; u < KI; ++u)
+      if (kitem[u]) st16(Ks + klds[u], rk[u]);
     // V^T tile: [DVP dv][KB keys (permuted inside every 32-key chunk)]
+    // (a quad-major lane order would make these 8-byte writes bank-conflict-free, but it scatters
+    // the global loads over 64 rows per instruction and measured slower: 1.71 vs 1.61 ms)
+    const unsigned ones = DT == CA_F16 ? 0x3C003C00u : 0x3F803F80u;
 #pragma unroll
     for (int u = 0; u < VI; ++u) {
-      const int it = tid + u * NT;
-      if (it < (KB / 4) * (DVP / 8)) {
-        // (a quad-major lane order would make these 8-byte writes bank-conflict-free, but it scatters
-        // the global loads over 64 rows per instruction and measured slower: 1.71 vs 1.61 ms)
-        const int quad = it / (DVP / 8), dc = it - quad * (DVP / 8);
-        const int pos = (quad >> 3) * 32 + (quad & 3) * 8 + ((quad >> 2) & 1) * 4;
-        const int i_one = p.sum_row ? p.head_dim - dc * 8 : -1;  // the all-ones row, if it falls in this chunk
-        const unsigned ones = DT == CA_F16 ? 0x3C003C00u : 0x3F803F80u;
+      if (vitem[u]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int w = i >> 1;
@@ -147,8 +162,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
             o[0] = (rv[u][0][w] & 0xffffu) | (rv[u][1][w] << 16);
             o[1] = (rv[u][2][w] & 0xffffu) | (rv[u][3][w] << 16);
           }
-          if (i == i_one) o = (u32x2){ones, ones};
-          *reinterpret_cast<u32x2*>(Vts + (dc * 8 + i) * VLD + pos) = o;
+          if (i == vone[u]) o = (u32x2){ones, ones};
+          *reinterpret_cast<u32x2*>(Vts + vlds[u] + i * VLD) = o;
         }
       }
     }
@@ -160,8 +175,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     __syncthreads();
     if (KB < p.nk) load_tile(KB);
   }
-  int iter = 0;
-  for (int kv0 = 0; kv0 < p.nk; kv0 += KB, ++iter) {
+  // One tile of the KV loop.  `tail_c` is a compile-time flag: full tiles carry no key masking at all
+  // (hipcc if-converts a runtime `if (tail)` into ~115 compare/select instructions per tile).
+  auto tile_body = [&](int kv0, int iter, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
     const int buf = PF ? (iter & 1) : 0;
     if (!PF) {
       __syncthreads();
@@ -193,10 +210,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     // of a max and of a pack; masking only in the tail tile; row sums come out of the PV MFMA via
     // the all-ones V^T row when there is a spare padded row (sum_row).
     u32x4 pf[QT][KC];
-    const bool tail = kv0 + KB > p.nk;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      if (tail) {
+      if (TAIL) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -255,6 +271,12 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
       __syncthreads();
       if (kv0 + 2 * KB < p.nk) load_tile(kv0 + 2 * KB);
     }
+  };
+  {
+    const int nfull = p.nk / KB;
+    int iter = 0;
+    for (; iter < nfull; ++iter) tile_body(iter * KB, iter, BoolC<false>{});
+    if (nfull * KB < p.nk) tile_body(nfull * KB, iter, BoolC<true>{});
   }
 
   // ---- epilogue: lane holds O[q = .. + l15][dv = dt*16 + 4g + r] ------------------------------

@@ -247,11 +247,14 @@ def timestep_embedding(t, batch: int, dim: int, dtype: torch.dtype, device) -> t
     return out
 
 
-def latents_to_nhwc(latents: torch.Tensor, cpad: int, rep: int, in_scale: float, dtype: torch.dtype) -> torch.Tensor:
+def latents_to_nhwc(latents: torch.Tensor, cpad: int, rep: int, in_scale: float, dtype: torch.dtype,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req_cuda(latents)
     assert latents.dtype == torch.float32 and latents.is_contiguous() and latents.dim() == 5
     b0, c, f, h, w = latents.shape
-    out = torch.empty((rep * b0 * f, h, w, cpad), device=latents.device, dtype=dtype)
+    if out is None:
+        out = torch.empty((rep * b0 * f, h, w, cpad), device=latents.device, dtype=dtype)
+    assert out.shape == (rep * b0 * f, h, w, cpad) and out.dtype == dtype and out.is_contiguous()
     check(lib().ca_latents_to_nhwc(latents.data_ptr(), out.data_ptr(), b0, c, f, h, w, cpad, rep, in_scale,
                                    dt_code(dtype), _stream()), "ca_latents_to_nhwc")
     return out

@@ -181,10 +181,12 @@ class HipModelMixin:
     def _time_embedding(self, timestep, groups: int, device, timestep_cond=None) -> torch.Tensor:
         """-> silu(emb) projected through every resnet's time_emb_proj: fp32 [groups, sum C_out]."""
         dim = self.time_proj.num_channels
-        if torch.is_tensor(timestep) and timestep.numel() > 1:
-            if timestep.numel() != groups:
+        if torch.is_tensor(timestep) and (timestep.numel() > 1 or timestep.is_cuda):
+            # per-element timesteps, or a DEVICE scalar (keeps the value out of the launch arguments so a
+            # captured hipGraph of the step can be replayed with a new timestep)
+            if timestep.numel() not in (1, groups):
                 raise ValueError("timestep tensor must be a scalar or one value per batch element")
-            t = timestep.to(device=device, dtype=torch.float32).contiguous()
+            t = timestep.to(device=device, dtype=torch.float32).reshape(-1).expand(groups).contiguous()
             t_emb = K.timestep_embedding(t, groups, dim, self.act_dtype, device)
         else:
             tv = float(timestep.item()) if torch.is_tensor(timestep) else float(timestep)
