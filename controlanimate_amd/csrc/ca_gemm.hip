@@ -357,7 +357,7 @@ constexpr unsigned DMA_OOB = 0xFFFFFFF0u;  // beyond any descriptor size we acce
 //           then a raw s_barrier: DMA transfers stay in flight across barriers
 //           (cdna_hip_programming.md "Pipelining across barriers").  All LDS is one array.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF>
-__global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void k_gemm_dma(GemmKParams p) {
+__global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_gemm_dma(GemmKParams p) {
   constexpr int TM = BM / WAVES_M / 16;
   constexpr int TN = BN / WAVES_N / 16;
   constexpr int AG = BM / 32;  // 8-row groups staged per wave (A)
@@ -544,6 +544,14 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   int nbuf = nbuf_env ? nbuf_env : (blocks >= 512 ? 1 : 2);
   if (nbuf < 1 || nbuf > 4) nbuf = 2;
   if (nbuf > 2 && nt < nbuf) nbuf = 2;
+  // N = 320 / 960 (every projection and conv of the 64x64-latent level): 128x160 tiles divide N
+  // exactly and read the A panel 2 / 6 times instead of 5 / 15 times
+  static const int t160_env = getenv("CA_GEMM_T160") ? atoi(getenv("CA_GEMM_T160")) : 1;
+  if (dma && !wide && t160_env && p.n % 160 == 0 && (int64_t)ceil_div_i(p.m, 128) * (p.n / 160) >= 512) {
+    const dim3 grid(ceil_div_i(p.m, 128) * (p.n / 160));
+    hipLaunchKernelGGL((k_gemm_dma<DT, 128, 160, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
+    return CA_OK;
+  }
   if (wide) {
     const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128));
     if (!dma) hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, st, p);
