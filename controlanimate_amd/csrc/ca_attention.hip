@@ -13,6 +13,9 @@
 // a batch element) and temporal attention (strided rows) via the batch/row strides.
 #include "ca_common.h"
 #include <stdlib.h>
+#ifndef CA_ATTN_SETPRIO
+#define CA_ATTN_SETPRIO 0  // measured: no gain on this kernel (1.67 vs 1.61 ms)
+#endif
 
 namespace {
 
@@ -41,6 +44,7 @@ struct AttnKParams {
 template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool PF>
 __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   constexpr int NT = NW * 64;
+  constexpr bool SETPRIO = CA_ATTN_SETPRIO;  // raise wave priority around the MFMA clusters (T5)
   constexpr int DKP = DK32 * 32;
   constexpr int DVP = DV16 * 16;
   constexpr int KLD = DKP + 8;  // K tile row stride (elements)
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     for (int t = 0; t < QT; ++t)
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) sacc[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
         for (int t = 0; t < QT; ++t) sacc[t][kt] = Elem<DT>::mfma(kf, qf[t][kc], sacc[t][kt]);
       }
     }
+    if (SETPRIO) __builtin_amdgcn_s_setprio(0);
 
     // ---- online softmax (per lane = per query column) and P^T fragments ---------------------
     // VALU budget matters as much as MFMA at head_dim 40: per score one fma + one v_exp + a share
@@ -257,6 +263,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     }
 
     // ---- O^T += V^T P^T -------------------------------------------------------------------
+    if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int dt = 0; dt < DV16; ++dt) {
 #pragma unroll
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
         for (int t = 0; t < QT; ++t) oacc[t][dt] = Elem<DT>::mfma(vf, pf[t][c], oacc[t][dt]);
       }
     }
+    if (SETPRIO) __builtin_amdgcn_s_setprio(0);
     if (PF) {
       if (kv0 + KB < p.nk) store_tile(buf ^ 1);
       __syncthreads();

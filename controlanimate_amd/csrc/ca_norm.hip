@@ -7,15 +7,17 @@ namespace {
 constexpr int GN_MAX_SLOTS = 5;  // 64 lanes * 8 channels * 5 = 2560 channels
 constexpr int GN_MAX_C = 64 * 8 * GN_MAX_SLOTS;
 
-// Row chunks per statistics group: ~64 rows per block for big images, down to 4 rows per block for
-// the 8x8 / 16x16 latent levels (otherwise a [32, 8, 8, 1280] tensor would run on 32 blocks).
-inline int gn_chunks_host(int64_t rows_per_stat) {
-  int64_t n = (rows_per_stat + 63) / 64;
+// Row chunks per statistics group.  The statistics pass uses ~256-row chunks (its per-block
+// reduction is amortised over more rows), the apply pass ~64-row chunks; both go down to 4 rows per
+// block for the 8x8 / 16x16 latent levels (a [32, 8, 8, 1280] tensor would otherwise run on 32 blocks).
+inline int gn_chunks_rows(int64_t rows_per_stat, int rows_per_chunk) {
+  int64_t n = (rows_per_stat + rows_per_chunk - 1) / rows_per_chunk;
   if (n < 16) n = (rows_per_stat + 3) / 4 < 16 ? (rows_per_stat + 3) / 4 : 16;
   if (n < 1) n = 1;
   if (n > 256) n = 256;
   return (int)n;
 }
+inline int gn_chunks_host(int64_t rows_per_stat) { return gn_chunks_rows(rows_per_stat, 256); }
 
 struct GnParams {
   const u16* x;
@@ -26,19 +28,35 @@ struct GnParams {
   float* partials;
   int c1, c2, groups;
   int64_t rows_per_stat;  // frames_per_stat * hw
-  int nchunks;
-  int64_t rows_per_chunk;
+  int nchunks;             // chunks of the statistics pass (= partial sums per group)
+  int64_t rows_per_chunk;  // rows per block of the kernel being launched
   float eps;
   int act;
 };
 
-// grid: (nchunks, n_stat_groups). block 256 = 64 channel-chunk lanes x 4 row lanes.
-template <int DT>
+// Thread mapping: tx = lane over 16-byte channel chunks, ty = lane over rows; TX = 2^txlog is chosen
+// so that C/8 = TX * slots with slots <= 5 and (almost) no idle lanes: C = 320/640/1280 -> TX = 8/16/32
+// with 5 slots (a 64-wide mapping would idle 37% of the lanes at C = 320), otherwise TX = 64.  256/TX
+// rows are in flight per block iteration, every thread issuing all its slot loads back to back.
+__host__ __device__ inline int gn_txlog(int c8) {
+  if (c8 % 5 == 0) {
+    const int q = c8 / 5;
+    if (q == 8) return 3;
+    if (q == 16) return 4;
+    if (q == 32) return 5;
+  }
+  return 6;
+}
+
+// grid: (nchunks, n_stat_groups)
+template <int DT, int txlog>
 __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
   __shared__ float ch_s[GN_MAX_C];
   __shared__ float ch_ss[GN_MAX_C];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int C = p.c1 + p.c2, C8 = C >> 3;
+  constexpr int TX = 1 << txlog, TY = 256 >> txlog;
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> txlog;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int chunk = blockIdx.x, sg = blockIdx.y;
   const int64_t r0 = (int64_t)chunk * p.rows_per_chunk;
   int64_t r1 = r0 + p.rows_per_chunk;
@@ -51,16 +69,22 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[k][j] = ss[k][j] = 0.f;
 
-  for (int64_t r = r0 + ty; r < r1; r += 4) {
+  for (int64_t r = r0 + ty; r < r1; r += TY) {
     const int64_t row = base_row + r;
+    u32x4 raw[GN_MAX_SLOTS];
 #pragma unroll
     for (int k = 0; k < GN_MAX_SLOTS; ++k) {
-      const int c8 = tx + 64 * k;
+      const int c8 = tx + (k << txlog);
       if (c8 < C8) {
         const int ch = c8 << 3;
-        const u16* src = ch < p.c1 ? p.x + row * p.c1 + ch : p.x2 + row * p.c2 + (ch - p.c1);
+        raw[k] = ld16(ch < p.c1 ? p.x + row * p.c1 + ch : p.x2 + row * p.c2 + (ch - p.c1));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      if (tx + (k << txlog) < C8) {
         float f[8];
-        unpack8<DT>(ld16(src), f);
+        unpack8<DT>(raw[k], f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           s[k][j] += f[j];
@@ -69,12 +93,26 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
       }
     }
   }
-  // deterministic cross-wave reduction through LDS, one wave at a time
+  // deterministic reduction: row lanes of one wave by xor-shuffles (fixed tree), then the four waves
+  // one after the other through LDS
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+    if ((k << txlog) < C8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int off = TX; off < 64; off <<= 1) {
+          s[k][j] += __shfl_xor(s[k][j], off);
+          ss[k][j] += __shfl_xor(ss[k][j], off);
+        }
+      }
+    }
+  }
   for (int w = 0; w < 4; ++w) {
-    if (ty == w) {
+    if (wave == w && lane < TX) {
 #pragma unroll
       for (int k = 0; k < GN_MAX_SLOTS; ++k) {
-        const int c8 = tx + 64 * k;
+        const int c8 = tx + (k << txlog);
         if (c8 < C8) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -105,13 +143,14 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
   }
 }
 
-template <int DT>
+template <int DT, int txlog>
 __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
   __shared__ float sc[GN_MAX_C];
   __shared__ float sh[GN_MAX_C];
   __shared__ float gm[64], gr[64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int C = p.c1 + p.c2, C8 = C >> 3;
+  constexpr int TX = 1 << txlog, TY = 256 >> txlog;
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> txlog;
   const int chunk = blockIdx.x, sg = blockIdx.y;
   const int cpg = C / p.groups;
   if (threadIdx.x < p.groups) {
@@ -136,27 +175,46 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
     sh[c] = p.beta[c] - gm[gi] * scale;
   }
   __syncthreads();
-
+  // this thread's channels are the same for every row: keep their scale/shift in registers
+  float rs[GN_MAX_SLOTS][8], rh[GN_MAX_SLOTS][8];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+    const int c8 = tx + (k << txlog);
+    if (c8 < C8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        rs[k][j] = sc[(c8 << 3) + j];
+        rh[k][j] = sh[(c8 << 3) + j];
+      }
+    }
+  }
   const int64_t r0 = (int64_t)chunk * p.rows_per_chunk;
   int64_t r1 = r0 + p.rows_per_chunk;
   if (r1 > p.rows_per_stat) r1 = p.rows_per_stat;
   const int64_t base_row = (int64_t)sg * p.rows_per_stat;
-  for (int64_t r = r0 + ty; r < r1; r += 4) {
+  for (int64_t r = r0 + ty; r < r1; r += TY) {
     const int64_t row = base_row + r;
+    u32x4 raw[GN_MAX_SLOTS];
 #pragma unroll
     for (int k = 0; k < GN_MAX_SLOTS; ++k) {
-      const int c8 = tx + 64 * k;
+      const int c8 = tx + (k << txlog);
       if (c8 < C8) {
         const int ch = c8 << 3;
-        const u16* src = ch < p.c1 ? p.x + row * p.c1 + ch : p.x2 + row * p.c2 + (ch - p.c1);
+        raw[k] = ld16(ch < p.c1 ? p.x + row * p.c1 + ch : p.x2 + row * p.c2 + (ch - p.c1));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      const int c8 = tx + (k << txlog);
+      if (c8 < C8) {
         float f[8];
-        unpack8<DT>(ld16(src), f);
+        unpack8<DT>(raw[k], f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float v = f[j] * sc[ch + j] + sh[ch + j];
+          const float v = f[j] * rs[k][j] + rh[k][j];
           f[j] = p.act == CA_ACT_SILU ? silu_f(v) : v;
         }
-        st16(p.y + row * C + ch, pack8<DT>(f));
+        st16(p.y + row * C + (c8 << 3), pack8<DT>(f));
       }
     }
   }
@@ -334,13 +392,32 @@ extern "C" int64_t ca_groupnorm_partials_floats(int32_t images, int32_t hw, int3
   return nstat * gn_chunks_host((int64_t)frames_per_stat * hw) * groups * 2;
 }
 
+template <int DT>
+void launch_gn(bool apply, const GnParams& p, dim3 grid, hipStream_t st) {
+  const int txlog = gn_txlog((p.c1 + p.c2) >> 3);
+#define CA_GN_CASE(L)                                                                         \
+  case L:                                                                                     \
+    if (apply) hipLaunchKernelGGL((k_gn_apply<DT, L>), grid, dim3(256), 0, st, p);            \
+    else hipLaunchKernelGGL((k_gn_stats<DT, L>), grid, dim3(256), 0, st, p);                  \
+    break;
+  switch (txlog) {
+    CA_GN_CASE(3)
+    CA_GN_CASE(4)
+    CA_GN_CASE(5)
+    default:
+      if (apply) hipLaunchKernelGGL((k_gn_apply<DT, 6>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_gn_stats<DT, 6>), grid, dim3(256), 0, st, p);
+  }
+#undef CA_GN_CASE
+}
+
 extern "C" int ca_groupnorm_stats(const ca_groupnorm_args* a, void* stream) {
   GnParams p{};
   int rc = gn_fill(a, p, "ca_groupnorm_stats");
   if (rc) return rc;
   dim3 grid(p.nchunks, a->images / a->frames_per_stat);
-  if (a->dtype == CA_BF16) hipLaunchKernelGGL(k_gn_stats<CA_BF16>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(k_gn_stats<CA_F16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (a->dtype == CA_BF16) launch_gn<CA_BF16>(false, p, grid, (hipStream_t)stream);
+  else launch_gn<CA_F16>(false, p, grid, (hipStream_t)stream);
   CA_CHECK_LAUNCH("ca_groupnorm_stats");
   return CA_OK;
 }
@@ -350,9 +427,11 @@ extern "C" int ca_groupnorm_apply(const ca_groupnorm_args* a, void* stream) {
   int rc = gn_fill(a, p, "ca_groupnorm_apply");
   if (rc) return rc;
   CA_REQUIRE(a->y && a->gamma && a->beta, "ca_groupnorm_apply: null operand");
-  dim3 grid(p.nchunks, a->images / a->frames_per_stat);
-  if (a->dtype == CA_BF16) hipLaunchKernelGGL(k_gn_apply<CA_BF16>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(k_gn_apply<CA_F16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  const int achunks = gn_chunks_rows(p.rows_per_stat, 64);
+  p.rows_per_chunk = (p.rows_per_stat + achunks - 1) / achunks;
+  dim3 grid(achunks, a->images / a->frames_per_stat);
+  if (a->dtype == CA_BF16) launch_gn<CA_BF16>(true, p, grid, (hipStream_t)stream);
+  else launch_gn<CA_F16>(true, p, grid, (hipStream_t)stream);
   CA_CHECK_LAUNCH("ca_groupnorm_apply");
   return CA_OK;
 }

@@ -63,8 +63,8 @@ def test_invalid_arguments_are_rejected_without_a_gpu(capi):
     args = capi.GemmArgs(m=0, n=0, k1=0, k2=0)
     rc = lib.ca_gemm(C.byref(args), None)
     assert rc == -1 and b"ca_gemm" in lib.ca_last_error()
-    assert lib.ca_groupnorm_partials_floats(32, 4096, 1, 32) == 32 * 64 * 32 * 2
-    assert lib.ca_groupnorm_partials_floats(2, 4096, 2, 32) == 1 * 128 * 32 * 2
+    assert lib.ca_groupnorm_partials_floats(32, 4096, 1, 32) == 32 * 16 * 32 * 2   # 256-row chunks
+    assert lib.ca_groupnorm_partials_floats(2, 4096, 2, 32) == 1 * 32 * 32 * 2
     assert lib.ca_groupnorm_partials_floats(32, 64, 1, 32) == 32 * 16 * 32 * 2  # small images: 4 rows per chunk
 
 
