@@ -47,6 +47,20 @@ struct GemmKParams {
 
 constexpr int BK = 64;
 
+// Tile order inside an XCD's contiguous id range: groups of GROUP_M row-tiles are swept column by
+// column, so the ~128 blocks resident on an XCD share 8 A panels and ~16 W panels in its 4 MB L2.
+// (With a plain row-major order every row-tile streamed the whole weight matrix again: measured
+// FETCH_SIZE 1.6 GB for the 8192x10240x1280 GEGLU GEMM whose operands total 47 MB.)
+constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_coords(unsigned bid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+  const unsigned gsz = GROUP_M * tiles_n;
+  const unsigned group = bid / gsz, in = bid - group * gsz;
+  const int first_m = group * GROUP_M;
+  const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+  tile_m = first_m + in % gm;
+  tile_n = in / gm;
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
@@ -227,7 +241,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmKParams p) {
 
   const int tiles_n = (p.n + BN - 1) / BN;
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  int tile_m, tile_n;
+  tile_coords(bid, (p.m + BM - 1) / BM, tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- loader setup -------------------------------------------------------------------
@@ -374,7 +389,8 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_g
 
   const int tiles_n = (p.n + BN - 1) / BN;
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  int tile_m, tile_n;
+  tile_coords(bid, (p.m + BM - 1) / BM, tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
