@@ -13,6 +13,9 @@
 // a batch element) and temporal attention (strided rows) via the batch/row strides.
 #include "ca_common.h"
 #include <stdlib.h>
+#ifndef CA_ATTN_ABLATE
+#define CA_ATTN_ABLATE 0  // timing experiments only: 1 no exp, 2 no PV MFMA, 3 no K/V staging after tile 0, 4 no QK MFMA
+#endif
 #ifndef CA_ATTN_SETPRIO
 #define CA_ATTN_SETPRIO 0  // measured: no gain on this kernel (1.67 vs 1.61 ms)
 #endif
@@ -200,13 +203,15 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) sacc[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+    // kc outer / kt inner: MFMAs that accumulate into the same S^T tile are KT*QT instructions apart
+    // (back-to-back dependent 16x16x32 MFMAs stall ~2x: measured 29 instead of 16 cycles each)
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kc = 0; kc < DK32; ++kc) {
 #pragma unroll
-      for (int kc = 0; kc < DK32; ++kc) {
+      for (int kt = 0; kt < KT; ++kt) {
         const u32x4 kf = ld16(Ks + (kt * 16 + l15) * KLD + kc * 32 + g * 8);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) sacc[t][kt] = Elem<DT>::mfma(kf, qf[t][kc], sacc[t][kt]);
+        for (int t = 0; t < QT; ++t) { if (CA_ATTN_ABLATE == 4) { sacc[t][kt][0] += __builtin_bit_cast(float, kf[0] ^ qf[t][kc][0]); } else sacc[t][kt] = Elem<DT>::mfma(kf, qf[t][kc], sacc[t][kt]); }
       }
     }
     if (SETPRIO) __builtin_amdgcn_s_setprio(0);
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
+        for (int r = 0; r < 4; ++r) sacc[t][kt][r] = CA_ATTN_ABLATE == 1 ? fmaf(sacc[t][kt][r], p.scale_log2, nmc) : __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
       if (!p.sum_row) {
         float psum = 0.f;
 #pragma unroll
@@ -265,19 +270,19 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     // ---- O^T += V^T P^T -------------------------------------------------------------------
     if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int dt = 0; dt < DV16; ++dt) {
+    for (int c = 0; c < KC; ++c) {
 #pragma unroll
-      for (int c = 0; c < KC; ++c) {
+      for (int dt = 0; dt < DV16; ++dt) {
         const u32x4 vf = ld16(Vts + (dt * 16 + l15) * VLD + c * 32 + g * 8);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) oacc[t][dt] = Elem<DT>::mfma(vf, pf[t][c], oacc[t][dt]);
+        for (int t = 0; t < QT; ++t) { if (CA_ATTN_ABLATE == 2) { oacc[t][dt][0] += __builtin_bit_cast(float, vf[0] ^ pf[t][c][0]); } else oacc[t][dt] = Elem<DT>::mfma(vf, pf[t][c], oacc[t][dt]); }
       }
     }
     if (SETPRIO) __builtin_amdgcn_s_setprio(0);
     if (PF) {
-      if (kv0 + KB < p.nk) store_tile(buf ^ 1);
+      if (CA_ATTN_ABLATE != 3) { if (kv0 + KB < p.nk) store_tile(buf ^ 1); }
       __syncthreads();
-      if (kv0 + 2 * KB < p.nk) load_tile(kv0 + 2 * KB);
+      if (CA_ATTN_ABLATE != 3) { if (kv0 + 2 * KB < p.nk) load_tile(kv0 + 2 * KB); }
     }
   };
   {
@@ -324,6 +329,230 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the long-sequence case (spatial self-attention, N >= 1024; head_dim <= 64).
+// K and V tiles are copied global -> LDS row-major by `buffer_load_dwordx4 ... lds` (no VGPR round
+// trip, no ds_write pass, no register transposition: staging was 30% of the register-staged kernel).
+//   * rows are 128 B (64 elements); the 16-byte chunk is XOR-swizzled with (row>>1)&7 on the DMA
+//     source side and on every read, as in ca_gemm.hip;
+//   * chunks beyond head_dim are never transferred (exec-masked) -- the pad region is zeroed once;
+//     keys beyond nk get an out-of-range offset -> the hardware writes zeros;
+//   * V^T MFMA A-fragments come from the row-major V tile with the gfx950 transpose read
+//     ds_read_b64_tr_b16: inside a 16-lane group lane p supplies the address of piece p of a
+//     [4 keys][16 dv] block (row p/4, 4 columns at 4*(p%4)) and receives column p, i.e. 4 keys of one
+//     dv (semantics probed on MI355X: tools/probe_tr.hip).  Two reads (keys 4g.. and 16+4g..) give the 8
+//     keys of the fragment in exactly the order the P^T fragment holds them.
+//   * two LDS buffers, the next tile's DMA is issued before the MFMA phase; one barrier per tile.
+template <int DT, int DK32, int DV16, int QT, int NW, int KB>
+__global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
+  constexpr int ROW = 64;                 // LDS row length (elements): head_dim <= 64
+  constexpr int KT = KB / 16, KC = KB / 32;
+  constexpr int TILE = 2 * KB * ROW;      // K tile + V tile
+  constexpr int GRP = KB / 8 / NW;        // 8-row DMA groups per wave per operand
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * TILE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  unsigned bid = blockIdx.x;
+  const int qb = bid % p.qblocks;
+  bid /= p.qblocks;
+  const int head = bid % p.heads;
+  const int z = bid / p.heads;
+  const int zo = z / p.inner_count, zi = z - zo * p.inner_count;
+  const int zk = (z / p.kv_div) % p.kv_mod;
+  const int zko = zk / p.kv_inner_count, zki = zk - zko * p.kv_inner_count;
+  const u16* qp = p.q + zo * p.q_outer + zi * p.q_inner + (int64_t)head * p.head_dim;
+  u16* op = p.o + zo * p.o_outer + zi * p.o_inner + (int64_t)head * p.head_dim;
+  const int64_t kvoff = zko * p.k_outer + zki * p.k_inner + (int64_t)head * p.head_dim;
+  const u16* kp = p.k + kvoff;
+  const u16* vp = p.v + kvoff;
+  const unsigned kv_bytes = (unsigned)(((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2);
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, kv_bytes, 0x00020000);
+
+  const int q0 = qb * (NW * QT * 16) + wid * (QT * 16);
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // zero both buffers once: the pad chunks (d >= head_dim) are never written again
+  for (int i = tid; i < 2 * TILE / 8; i += NW * 64) st16(smem + i * 8, zero4);
+
+  u32x4 qf[QT][DK32];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qi = q0 + t * 16 + l15;
+#pragma unroll
+    for (int kc = 0; kc < DK32; ++kc) {
+      const int d = kc * 32 + g * 8;
+      qf[t][kc] = (qi < p.nq && d < p.head_dim) ? ld16(qp + (int64_t)qi * p.q_row + d) : zero4;
+    }
+  }
+
+  // DMA lane assignment: 8 rows x 8 chunks per wave instruction
+  const int r8 = lane >> 3, cpos = lane & 7;
+  int d_row[GRP];
+  unsigned d_off[GRP];
+  bool d_ok[GRP];
+#pragma unroll
+  for (int i = 0; i < GRP; ++i) {
+    const int row = (wid * GRP + i) * 8 + r8;
+    const int chunk = cpos ^ ((row >> 1) & 7);
+    d_row[i] = row;
+    d_ok[i] = chunk * 8 < p.head_dim;
+    d_off[i] = (unsigned)((int64_t)row * p.k_row * 2 + chunk * 16);
+  }
+  const unsigned tile_adv = (unsigned)((int64_t)KB * p.k_row * 2);
+  auto stage = [&](int kv0, int buf) {
+    u16* Ks = smem + buf * TILE;
+    u16* Vs = Ks + KB * ROW;
+    const unsigned adv = (unsigned)(kv0 / KB) * tile_adv;
+#pragma unroll
+    for (int i = 0; i < GRP; ++i) {
+      if (d_ok[i]) {
+        const unsigned off = (kv0 + d_row[i] < p.nk) ? d_off[i] + adv : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(Ks + (wid * GRP + i) * 8 * ROW), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (__attribute__((address_space(3))) void*)(Vs + (wid * GRP + i) * 8 * ROW), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 oacc[QT][DV16];
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    mrun[t] = -INFINITY;
+    lrun[t] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DV16; ++dt) oacc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  typedef short v4s __attribute__((ext_vector_type(4)));
+
+  __syncthreads();  // zero fill complete before the first transfer lands
+  stage(0, 0);
+  __syncthreads();  // (vmcnt(0) + barrier)
+
+  auto tile_body = [&](int kv0, int iter, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    const int buf = iter & 1;
+    if (kv0 + KB < p.nk) stage(kv0 + KB, buf ^ 1);
+    const u16* Ks = smem + buf * TILE;
+    const u16* Vs = Ks + KB * ROW;
+
+    f32x4 sacc[QT][KT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) sacc[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < DK32; ++kc) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int row = kt * 16 + l15;
+        const u32x4 kf = ld16(Ks + row * ROW + (((kc * 4 + g) ^ ((row >> 1) & 7)) << 3));
+#pragma unroll
+        for (int t = 0; t < QT; ++t) sacc[t][kt] = Elem<DT>::mfma(kf, qf[t][kc], sacc[t][kt]);
+      }
+    }
+
+    u32x4 pf[QT][KC];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (TAIL) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + kt * 16 + g * 4 + r >= p.nk) sacc[t][kt][r] = -INFINITY;
+      }
+      float mloc = fmaxf(fmaxf(sacc[t][0][0], sacc[t][0][1]), fmaxf(sacc[t][0][2], sacc[t][0][3]));
+#pragma unroll
+      for (int kt = 1; kt < KT; ++kt)
+        mloc = fmaxf(fmaxf(fmaxf(mloc, sacc[t][kt][0]), fmaxf(sacc[t][kt][1], sacc[t][kt][2])), sacc[t][kt][3]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      const float mnew = fmaxf(mrun[t], mloc);
+      const float nmc = -mnew * p.scale_log2;
+      const float alpha = __builtin_amdgcn_exp2f(fmaf(mrun[t], p.scale_log2, nmc));
+      mrun[t] = mnew;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sacc[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
+          psum += sacc[t][kt][r];
+        }
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      lrun[t] = lrun[t] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DV16; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[t][dt][r] *= alpha;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        pf[t][c][0] = pack2_prob<DT>(sacc[t][2 * c][0], sacc[t][2 * c][1]);
+        pf[t][c][1] = pack2_prob<DT>(sacc[t][2 * c][2], sacc[t][2 * c][3]);
+        pf[t][c][2] = pack2_prob<DT>(sacc[t][2 * c + 1][0], sacc[t][2 * c + 1][1]);
+        pf[t][c][3] = pack2_prob<DT>(sacc[t][2 * c + 1][2], sacc[t][2 * c + 1][3]);
+      }
+    }
+
+    // O^T += V^T P^T; V^T fragments by transpose reads of the row-major V tile
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+#pragma unroll
+      for (int dt = 0; dt < DV16; ++dt) {
+        const int col = dt * 16 + 4 * (l15 & 3);
+        const int r0 = c * 32 + 4 * g + (l15 >> 2), r1 = r0 + 16;
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(Vs + r0 * ROW + (((col >> 3) ^ ((r0 >> 1) & 7)) << 3) + (col & 7)));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(Vs + r1 * ROW + (((col >> 3) ^ ((r1 >> 1) & 7)) << 3) + (col & 7)));
+        const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+        const u32x4 vf = {lo2[0], lo2[1], hi2[0], hi2[1]};
+#pragma unroll
+        for (int t = 0; t < QT; ++t) oacc[t][dt] = Elem<DT>::mfma(vf, pf[t][c], oacc[t][dt]);
+      }
+    }
+    __syncthreads();  // next tile landed (vmcnt(0)) and this tile is no longer read
+  };
+  {
+    const int nfull = p.nk / KB;
+    int iter = 0;
+    for (; iter < nfull; ++iter) tile_body(iter * KB, iter, BoolC<false>{});
+    if (nfull * KB < p.nk) tile_body(nfull * KB, iter, BoolC<true>{});
+  }
+
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qi = q0 + t * 16 + l15;
+    if (qi >= p.nq) continue;
+    const float inv = p.out_scale / lrun[t];
+    u16* orow = op + (int64_t)qi * p.o_row;
+#pragma unroll
+    for (int dt = 0; dt < DV16; ++dt) {
+      const int dv = dt * 16 + g * 4;
+      if (dv >= p.head_dim) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = oacc[t][dt][r] * inv;
+      if (p.accumulate) {
+        u32x2 old = *reinterpret_cast<const u32x2*>(orow + dv);
+        v[0] += Elem<DT>::to_f((u16)(old[0] & 0xffffu));
+        v[1] += Elem<DT>::to_f((u16)(old[0] >> 16));
+        v[2] += Elem<DT>::to_f((u16)(old[1] & 0xffffu));
+        v[3] += Elem<DT>::to_f((u16)(old[1] >> 16));
+      }
+      u32x2 o;
+      o[0] = pack2<DT>(v[0], v[1]);
+      o[1] = pack2<DT>(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(orow + dv) = o;
+    }
+  }
+}
+
 template <int DT, int DK32, int DV16>
 void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
   AttnKParams p = p0;
@@ -338,6 +567,12 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
     static const int pf_env = getenv("CA_ATTN_PF") ? atoi(getenv("CA_ATTN_PF")) : 1;  // tuning knob
     p.qblocks = ceil_div_i(p.nq, 128);
     const dim3 grid((unsigned)(p.qblocks * p.batches * p.heads));
+    static const int dma_env = getenv("CA_ATTN_DMA") ? atoi(getenv("CA_ATTN_DMA")) : 1;
+    if (DK32 <= 2 && dma_env && p.nk >= 256 && p.k_row % 8 == 0 &&
+        ((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2 < (int64_t)0xFFFFFF00ll) {
+      hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64>), grid, dim3(256), 0, st, p);
+      return;
+    }
     static const int var_env = getenv("CA_ATTN_VAR") ? atoi(getenv("CA_ATTN_VAR")) : 0;  // experiments (d <= 48 only)
     if (DK32 == 2 && DV16 == 3 && var_env == 1) {  // KB = 128
       hipLaunchKernelGGL((k_attn<DT, 2, 3, 2, 4, 128, true>), grid, dim3(256), 0, st, p);
