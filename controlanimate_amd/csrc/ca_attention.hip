@@ -13,9 +13,6 @@
 // a batch element) and temporal attention (strided rows) via the batch/row strides.
 #include "ca_common.h"
 #include <stdlib.h>
-#ifndef CA_ATTN_ABLATE
-#define CA_ATTN_ABLATE 0  // timing experiments only: 1 no exp, 2 no PV MFMA, 3 no K/V staging after tile 0, 4 no QK MFMA
-#endif
 #ifndef CA_ATTN_SETPRIO
 #define CA_ATTN_SETPRIO 0  // measured: no gain on this kernel (1.67 vs 1.61 ms)
 #endif
@@ -96,10 +93,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   }
 
   f32x4 oacc[QT][DV16];
-  float mrun[QT], lrun[QT];
+  float mref[QT], lrun[QT];  // mref: reference maximum, already multiplied by scale*log2(e)
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    mrun[t] = -INFINITY;
+    mref[t] = -INFINITY;
     lrun[t] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DV16; ++dt) oacc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -211,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
       for (int kt = 0; kt < KT; ++kt) {
         const u32x4 kf = ld16(Ks + (kt * 16 + l15) * KLD + kc * 32 + g * 8);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) { if (CA_ATTN_ABLATE == 4) { sacc[t][kt][0] += __builtin_bit_cast(float, kf[0] ^ qf[t][kc][0]); } else sacc[t][kt] = Elem<DT>::mfma(kf, qf[t][kc], sacc[t][kt]); }
+        for (int t = 0; t < QT; ++t) sacc[t][kt] = Elem<DT>::mfma(kf, qf[t][kc], sacc[t][kt]);
       }
     }
     if (SETPRIO) __builtin_amdgcn_s_setprio(0);
@@ -220,7 +217,13 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     // VALU budget matters as much as MFMA at head_dim 40: per score one fma + one v_exp + a share
     // of a max and of a pack; masking only in the tail tile; row sums come out of the PV MFMA via
     // the all-ones V^T row when there is a spare padded row (sum_row).
+    // Deferred running maximum: the reference point mref (already in the exp2 domain) only moves when
+    // some score exceeds it by more than 2^8, so rescaling O is a rare wave-uniform branch, the common
+    // path has no cross-lane traffic, and p = 2^(s - mref) <= 256; the final division by the row sum
+    // makes the result independent of the reference point.
     u32x4 pf[QT][KC];
+    float mloc[QT];
+    bool grow = false;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       if (TAIL) {
@@ -230,34 +233,44 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
           for (int r = 0; r < 4; ++r)
             if (kv0 + kt * 16 + g * 4 + r >= p.nk) sacc[t][kt][r] = -INFINITY;
       }
-      float mloc = fmaxf(fmaxf(sacc[t][0][0], sacc[t][0][1]), fmaxf(sacc[t][0][2], sacc[t][0][3]));
+      float m = vmax3(sacc[t][0][0], sacc[t][0][1], sacc[t][0][2]);
+      m = vmax2(m, sacc[t][0][3]);
 #pragma unroll
-      for (int kt = 1; kt < KT; ++kt)
-        mloc = fmaxf(fmaxf(fmaxf(mloc, sacc[t][kt][0]), fmaxf(sacc[t][kt][1], sacc[t][kt][2])), sacc[t][kt][3]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-      const float mnew = fmaxf(mrun[t], mloc);
-      const float nmc = -mnew * p.scale_log2;
-      const float alpha = __builtin_amdgcn_exp2f(fmaf(mrun[t], p.scale_log2, nmc));
-      mrun[t] = mnew;
+      for (int kt = 1; kt < KT; ++kt) {
+        m = vmax3(m, sacc[t][kt][0], sacc[t][kt][1]);
+        m = vmax3(m, sacc[t][kt][2], sacc[t][kt][3]);
+      }
+      mloc[t] = m;
+      grow |= m * p.scale_log2 > mref[t] + 8.0f;
+    }
+    if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        const float mnew = fmaxf(mref[t], rowgroup_max(mloc[t]) * p.scale_log2);
+        const float alpha = __builtin_amdgcn_exp2f(mref[t] - mnew);
+        mref[t] = mnew;
+        lrun[t] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DV16; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[t][dt][r] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const float nmc = -mref[t];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[t][kt][r] = CA_ATTN_ABLATE == 1 ? fmaf(sacc[t][kt][r], p.scale_log2, nmc) : __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
+        for (int r = 0; r < 4; ++r) sacc[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
       if (!p.sum_row) {
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) psum += sacc[t][kt][r];
-        psum += __shfl_xor(psum, 16);
-        psum += __shfl_xor(psum, 32);
-        lrun[t] = lrun[t] * alpha + psum;
+        lrun[t] += psum;  // per-lane partial; the four row groups are added in the epilogue
       }
-#pragma unroll
-      for (int dt = 0; dt < DV16; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[t][dt][r] *= alpha;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         pf[t][c][0] = pack2_prob<DT>(sacc[t][2 * c][0], sacc[t][2 * c][1]);
@@ -275,14 +288,14 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
       for (int dt = 0; dt < DV16; ++dt) {
         const u32x4 vf = ld16(Vts + (dt * 16 + l15) * VLD + c * 32 + g * 8);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) { if (CA_ATTN_ABLATE == 2) { oacc[t][dt][0] += __builtin_bit_cast(float, vf[0] ^ pf[t][c][0]); } else oacc[t][dt] = Elem<DT>::mfma(vf, pf[t][c], oacc[t][dt]); }
+        for (int t = 0; t < QT; ++t) oacc[t][dt] = Elem<DT>::mfma(vf, pf[t][c], oacc[t][dt]);
       }
     }
     if (SETPRIO) __builtin_amdgcn_s_setprio(0);
     if (PF) {
-      if (CA_ATTN_ABLATE != 3) { if (kv0 + KB < p.nk) store_tile(buf ^ 1); }
+      if (kv0 + KB < p.nk) store_tile(buf ^ 1);
       __syncthreads();
-      if (CA_ATTN_ABLATE != 3) { if (kv0 + 2 * KB < p.nk) load_tile(kv0 + 2 * KB); }
+      if (kv0 + 2 * KB < p.nk) load_tile(kv0 + 2 * KB);
     }
   };
   {
@@ -297,6 +310,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   for (int t = 0; t < QT; ++t) {
     const int qi = q0 + t * 16 + l15;
     float lsum = lrun[t];
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
     if (p.sum_row) {  // row sums live in O^T[head_dim][q]: lanes of group (head_dim % 16) / 4, register 0
       float lv = 0.f;
 #pragma unroll
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
 //     dv (semantics probed on MI355X: tools/probe_tr.hip).  Two reads (keys 4g.. and 16+4g..) give the 8
 //     keys of the fragment in exactly the order the P^T fragment holds them.
 //   * two LDS buffers, the next tile's DMA is issued before the MFMA phase; one barrier per tile.
-template <int DT, int DK32, int DV16, int QT, int NW, int KB>
+template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool SR>
 __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   constexpr int ROW = 64;                 // LDS row length (elements): head_dim <= 64
   constexpr int KT = KB / 16, KC = KB / 32;
@@ -375,8 +390,20 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   const int q0 = qb * (NW * QT * 16) + wid * (QT * 16);
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  // zero both buffers once: the pad chunks (d >= head_dim) are never written again
+  // zero both buffers once: the pad chunks (d >= head_dim) are never written again.  SR (head_dim <
+  // 16*DV16): the first pad chunk of every V row holds ones instead, so row head_dim.. of O^T
+  // accumulates the softmax denominator in the MFMA (sum of the ROUNDED probabilities) for free.
   for (int i = tid; i < 2 * TILE / 8; i += NW * 64) st16(smem + i * 8, zero4);
+  if (SR) {
+    __syncthreads();
+    const unsigned one2 = DT == CA_F16 ? 0x3C003C00u : 0x3F803F80u;
+    const u32x4 ones4 = {one2, one2, one2, one2};
+    const int cs = p.head_dim >> 3;
+    for (int i = tid; i < 2 * KB; i += NW * 64) {
+      const int buf = i / KB, r = i - buf * KB;
+      st16(smem + buf * TILE + KB * ROW + r * ROW + ((cs ^ ((r >> 1) & 7)) << 3), ones4);
+    }
+  }
 
   u32x4 qf[QT][DK32];
 #pragma unroll
@@ -418,10 +445,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   };
 
   f32x4 oacc[QT][DV16];
-  float mrun[QT], lrun[QT];
+  float mref[QT], lrun[QT];  // mref: reference maximum, already multiplied by scale*log2(e)
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    mrun[t] = -INFINITY;
+    mref[t] = -INFINITY;
     lrun[t] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DV16; ++dt) oacc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -456,6 +483,13 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
     }
 
     u32x4 pf[QT][KC];
+    // Softmax in the exp2 domain with a DEFERRED running maximum (the reference point mref only moves
+    // when some score exceeds it by more than 2^8, so the rescale of O is a rare wave-uniform branch and
+    // p = 2^(s - mref) <= 256 stays well inside fp16/bf16 range; the final division by the row sum makes
+    // the result independent of the reference point).  No cross-lane traffic on the common path: each
+    // lane compares its own 16 scores with mref, the ballot ORs the lanes.
+    float mloc[QT];
+    bool grow = false;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       if (TAIL) {
@@ -465,31 +499,45 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
           for (int r = 0; r < 4; ++r)
             if (kv0 + kt * 16 + g * 4 + r >= p.nk) sacc[t][kt][r] = -INFINITY;
       }
-      float mloc = fmaxf(fmaxf(sacc[t][0][0], sacc[t][0][1]), fmaxf(sacc[t][0][2], sacc[t][0][3]));
+      float m = vmax3(sacc[t][0][0], sacc[t][0][1], sacc[t][0][2]);
+      m = vmax3(m, sacc[t][0][3], sacc[t][1][0]);
 #pragma unroll
-      for (int kt = 1; kt < KT; ++kt)
-        mloc = fmaxf(fmaxf(fmaxf(mloc, sacc[t][kt][0]), fmaxf(sacc[t][kt][1], sacc[t][kt][2])), sacc[t][kt][3]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-      const float mnew = fmaxf(mrun[t], mloc);
-      const float nmc = -mnew * p.scale_log2;
-      const float alpha = __builtin_amdgcn_exp2f(fmaf(mrun[t], p.scale_log2, nmc));
-      mrun[t] = mnew;
-      float psum = 0.f;
+      for (int kt = 1; kt < KT; ++kt) {
+        m = vmax3(m, sacc[t][kt][1], sacc[t][kt][2]);
+        if (kt + 1 < KT) m = vmax3(m, sacc[t][kt][3], sacc[t][kt + 1][0]);
+        else m = vmax2(m, sacc[t][kt][3]);
+      }
+      mloc[t] = m;
+      grow |= m * p.scale_log2 > mref[t] + 8.0f;
+    }
+    if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        const float mnew = fmaxf(mref[t], rowgroup_max(mloc[t]) * p.scale_log2);
+        const float alpha = __builtin_amdgcn_exp2f(mref[t] - mnew);
+        mref[t] = mnew;
+        if (!SR) lrun[t] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DV16; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[t][dt][r] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const float nmc = -mref[t];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sacc[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
-          psum += sacc[t][kt][r];
-        }
-      psum += __shfl_xor(psum, 16);
-      psum += __shfl_xor(psum, 32);
-      lrun[t] = lrun[t] * alpha + psum;
+        for (int r = 0; r < 4; ++r) sacc[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
+      if (!SR) {
+        float psum = 0.f;
 #pragma unroll
-      for (int dt = 0; dt < DV16; ++dt)
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[t][dt][r] *= alpha;
+          for (int r = 0; r < 4; ++r) psum += sacc[t][kt][r];
+        lrun[t] += psum;  // per-lane partial; the four row groups are added after the last tile
+      }
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         pf[t][c][0] = pack2_prob<DT>(sacc[t][2 * c][0], sacc[t][2 * c][1]);
@@ -528,8 +576,17 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int qi = q0 + t * 16 + l15;
+    float lsum;
+    if (SR) {  // the ones column is row head_dim of O^T: tile head_dim/16, row group (head_dim%16)/4, r = 0
+      const int hd = p.head_dim;
+      lsum = __shfl(oacc[t][DV16 - 1][0], ((hd & 15) >> 2) * 16 + l15);
+    } else {
+      lsum = lrun[t];
+      lsum += __shfl_xor(lsum, 16);
+      lsum += __shfl_xor(lsum, 32);
+    }
     if (qi >= p.nq) continue;
-    const float inv = p.out_scale / lrun[t];
+    const float inv = p.out_scale / lsum;
     u16* orow = op + (int64_t)qi * p.o_row;
 #pragma unroll
     for (int dt = 0; dt < DV16; ++dt) {
@@ -570,7 +627,11 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
     static const int dma_env = getenv("CA_ATTN_DMA") ? atoi(getenv("CA_ATTN_DMA")) : 1;
     if (DK32 <= 2 && dma_env && p.nk >= 256 && p.k_row % 8 == 0 &&
         ((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2 < (int64_t)0xFFFFFF00ll) {
-      hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64>), grid, dim3(256), 0, st, p);
+      // the ones column needs a free, 16-byte aligned pad chunk inside the last 16-wide dv tile
+      static const int sr_env = getenv("CA_ATTN_SR") ? atoi(getenv("CA_ATTN_SR")) : 1;
+      const bool sr = sr_env && p.head_dim % 8 == 0 && p.head_dim / 16 == DV16 - 1;
+      if (sr) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, false>), grid, dim3(256), 0, st, p);
       return;
     }
     static const int var_env = getenv("CA_ATTN_VAR") ? atoi(getenv("CA_ATTN_VAR")) : 0;  // experiments (d <= 48 only)

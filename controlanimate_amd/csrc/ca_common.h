@@ -102,6 +102,22 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// Three-/two-input max.  Written with fmaxf so the compiler sees the data dependence on MFMA results
+// (its hazard recogniser does not look inside inline asm: a hand-written v_max3_f32 read the
+// accumulators too early).  Files whose max chains consume MFMA output are compiled with
+// -fno-honor-nans, which drops the `v_max_f32 x, x, x` sNaN-quieting hipcc otherwise emits per input.
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float vmax2(float a, float b) { return fmaxf(a, b); }
+// max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: gfx950
+// v_permlane{32,16}_swap exchange half-waves / odd-even rows in the VALU (no LDS round trip).
+__device__ __forceinline__ float rowgroup_max(float m) {
+  unsigned u = __float_as_uint(m);
+  u32x2 a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = __float_as_uint(vmax2(__uint_as_float(a[0]), __uint_as_float(a[1])));
+  u32x2 b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return vmax2(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
