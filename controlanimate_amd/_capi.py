@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcontrolanimate_hip.so")
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class CAHipUnavailable(RuntimeError):
@@ -47,6 +47,7 @@ class ConvArgs(C.Structure):
         ("stride", C.c_int32), ("upsample", C.c_int32), ("rows_per_group", C.c_int32),
         ("alpha", C.c_float), ("post_scale", C.c_float),
         ("act", C.c_int32), ("out_f32", C.c_int32), ("dtype", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -91,6 +92,7 @@ SYMBOLS = {
     "ca_last_error": (C.c_char_p, []),
     "ca_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "ca_conv3x3": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "ca_conv3x3_workspace_bytes": (C.c_int64, [C.POINTER(ConvArgs)]),
     "ca_groupnorm_partials_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ca_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),
     "ca_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),

@@ -43,6 +43,11 @@ struct GemmKParams {
   int rows_per_group;
   float alpha, post;
   int act, geglu, out_f32;
+  // split-K (small-M convolutions): `splits` blocks share one output tile, each reduces a contiguous
+  // range of the K tiles into its own fp32 slab partial[split][m][n]; k_splitk_reduce adds the slabs
+  // in a fixed order and applies the epilogue (deterministic, no atomics)
+  int splits;
+  float* partial;
 };
 
 constexpr int BK = 64;
@@ -388,9 +393,15 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_g
   const int g = lane >> 4, l15 = lane & 15;
 
   const int tiles_n = (p.n + BN - 1) / BN;
-  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_m = (p.m + BM - 1) / BM;
+  unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  int split = 0;
+  if (p.splits > 1) {  // consecutive ids = the tiles of ONE K range (they share the weight slices)
+    split = bid / (unsigned)(tiles_m * tiles_n);
+    bid -= split * (unsigned)(tiles_m * tiles_n);
+  }
   int tile_m, tile_n;
-  tile_coords(bid, (p.m + BM - 1) / BM, tiles_n, tile_m, tile_n);
+  tile_coords(bid, tiles_m, tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
@@ -480,7 +491,9 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_g
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = p.taps * p.kc_tiles;
+  const int nt_all = p.taps * p.kc_tiles;
+  const int t_first = p.splits > 1 ? (int)((int64_t)nt_all * split / p.splits) : 0;
+  const int nt = (p.splits > 1 ? (int)((int64_t)nt_all * (split + 1) / p.splits) : nt_all) - t_first;
   auto compute = [&](int buf) {
     const u16* sa = smem + buf * (BM + BN) * BK;
     const u16* sb = sa + BM * BK;
@@ -501,17 +514,17 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_g
     // single LDS buffer (32 KB for 128x128): two barriers per tile, but 3 blocks per CU -- the
     // other resident blocks' MFMA phases cover this block's transfer latency
     for (int t = 0; t < nt; ++t) {
-      stage(t, 0);
+      stage(t_first + t, 0);
       __syncthreads();
       compute(0);
       __syncthreads();
     }
   } else if (NBUF == 2) {
-    stage(0, 0);
+    stage(t_first, 0);
     __syncthreads();  // hipcc drains the LDS-DMA queue (vmcnt(0)) ahead of the barrier
     for (int t = 0; t < nt; ++t) {
       const int buf = t & 1;
-      if (t + 1 < nt) stage(t + 1, buf ^ 1);
+      if (t + 1 < nt) stage(t_first + t + 1, buf ^ 1);
       compute(buf);
       __syncthreads();
     }
@@ -521,7 +534,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_g
     constexpr int PER_TILE = AG + BG;  // LDS-DMA instructions per wave per tile
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i)
-      if (i < nt) stage(i, i);
+      if (i < nt) stage(t_first + i, i);
     int buf = 0;
     for (int t = 0; t < nt; ++t) {
       const int younger = nt - 1 - t < NBUF - 2 ? nt - 1 - t : NBUF - 2;
@@ -530,13 +543,95 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_g
       else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER_TILE) : "memory");
       __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; tile t-1 is no longer read
-      if (t + NBUF - 1 < nt) stage(t + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
+      if (t + NBUF - 1 < nt) stage(t_first + t + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
       compute(buf);
       buf = buf == NBUF - 1 ? 0 : buf + 1;
     }
     __builtin_amdgcn_s_barrier();  // all fragment reads done before the epilogue reuses the LDS
   }
+  if (p.splits > 1) {  // raw fp32 slab; lane holds C[m = .. + l15][n = .. + 4g + (0..3)]
+    float* slab = p.partial + (int64_t)split * p.m * p.n;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * TM * 16 + i * 16 + l15;
+      if (m >= p.m) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 16 + j * 16 + g * 4;
+        if (n < p.n) *reinterpret_cast<f32x4*>(slab + (int64_t)m * p.n + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   gemm_epilogue<DT, BM, BN, TM, TN>(p, acc, smem, m0, n0, wm, wn, l15, g, tid);
+}
+
+// Adds the split-K slabs in split order and applies the same epilogue as gemm_epilogue (including its
+// rounding of (acc + bias + rowbias) * alpha to the activation type before the residual add).
+template <int DT>
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmKParams p) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c8n = p.n >> 3;
+  const int64_t m = id / c8n;
+  if (m >= p.m) return;
+  const int n = (int)(id - m * c8n) * 8;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = 0.f;
+  for (int sp = 0; sp < p.splits; ++sp) {
+    const float* src = p.partial + ((int64_t)sp * p.m + m) * p.n + n;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] += a[k];
+      v[4 + k] += b[k];
+    }
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += p.bias[n + k];
+  }
+  if (p.rowbias) {
+    const float* rbp = p.rowbias + (m / p.rows_per_group) * p.ld_rowbias + n;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += rbp[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] *= p.alpha;
+  unpack8<DT>(pack8<DT>(v), v);
+  if (p.res) {
+    float r[8];
+    unpack8<DT>(ld16(p.res + m * p.ld_res + n), r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += r[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] *= p.post;
+  if (p.act == CA_ACT_SILU) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = silu_f(v[k]);
+  }
+  const int64_t off = m * p.ldc + n;
+  if (p.out_f32) {
+    float* cp = reinterpret_cast<float*>(p.c) + off;
+    *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  } else {
+    st16(reinterpret_cast<u16*>(p.c) + off, pack8<DT>(v));
+  }
+}
+
+// Split-K plan for a launch: 1 = none.  Only grids that leave the chip under-filled (8x8 / 16x16 latent
+// levels) and have a long K loop are split; the tile shape used with a split is 128x128 (N % 128 == 0).
+inline int splitk_plan(int m, int n, int nt, int geglu) {
+  static const int env = getenv("CA_SPLITK") ? atoi(getenv("CA_SPLITK")) : -1;
+  if (env == 0 || geglu || n % 128 != 0) return 1;
+  const int64_t blocks = (int64_t)ceil_div_i(m, 128) * (n / 128);
+  if (blocks >= 384 || nt < 48) return 1;
+  int s = env > 0 ? env : (int)((960 + blocks - 1) / blocks);  // measured best on 160 tiles: 6 (89 vs 181 us unsplit)
+  if (s > 8) s = 8;
+  while (s > 1 && nt / s < 12) --s;
+  return s;
 }
 
 template <int DT, int MODE>
@@ -547,6 +642,12 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   static const int nbuf_env = getenv("CA_GEMM_NBUF") ? atoi(getenv("CA_GEMM_NBUF")) : 0;
   static const int bn_env = getenv("CA_GEMM_BN") ? atoi(getenv("CA_GEMM_BN")) : 0;
   const int nt = p.taps * p.kc_tiles;
+  if (dma && p.splits > 1) {
+    const int tiles = ceil_div_i(p.m, 128) * (p.n / 128);
+    hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 1>), dim3(tiles * p.splits), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_splitk_reduce<DT>), dim3(ceil_div_i((int64_t)p.m * (p.n / 8), 256)), dim3(256), 0, st, p);
+    return CA_OK;
+  }
   // 128x128 tiles unless N is not a multiple of 128 or the grid would leave CUs idle
   // (8x8 / 16x16 latent levels: M = 2048 / 8192 rows -> < 2 blocks per CU with the big tile).
   bool wide = p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128) >= 512;
@@ -642,11 +743,22 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   p.act = a->act;
   p.geglu = a->geglu;
   p.out_f32 = a->out_f32;
+  p.splits = 1;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 0>(p, st);
   else launch_gemm<CA_F16, 0>(p, st);
   CA_CHECK_LAUNCH("ca_gemm");
   return CA_OK;
+}
+
+extern "C" int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* a) {
+  if (!a || a->images <= 0 || a->hin <= 0 || a->win <= 0 || (a->stride != 1 && a->stride != 2)) return 0;
+  const int hl = a->hin << a->upsample, wl = a->win << a->upsample;
+  const int64_t m = (int64_t)a->images * ((hl + 2 - 3) / a->stride + 1) * ((wl + 2 - 3) / a->stride + 1);
+  const int kc = a->cin1 + a->cin2;
+  if (m >= (1ll << 31) || kc % BK != 0 || (a->cin2 != 0 && a->cin1 % BK != 0)) return 0;
+  const int s = splitk_plan((int)m, a->cout, 9 * ceil_div_i(kc, BK), 0);
+  return s > 1 ? (int64_t)s * m * a->cout * 4 : 0;
 }
 
 extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
@@ -699,6 +811,16 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
   p.act = a->act;
   p.geglu = 0;
   p.out_f32 = a->out_f32;
+  p.splits = 1;
+  {
+    const int kc = a->cin1 + a->cin2;
+    const bool dma_ok = kc % BK == 0 && (a->cin2 == 0 || a->cin1 % BK == 0) && p.a_bytes && p.w_bytes && (a->cin2 == 0 || p.a2_bytes);
+    const int s = dma_ok ? splitk_plan(p.m, p.n, 9 * p.kc_tiles, 0) : 1;
+    if (s > 1 && a->workspace && a->workspace_bytes >= (int64_t)s * p.m * p.n * 4) {
+      p.splits = s;
+      p.partial = (float*)a->workspace;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 1>(p, st);
   else launch_gemm<CA_F16, 1>(p, st);

@@ -107,6 +107,10 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
                     win=win, cin1=cin1, cin2=cin2, cout=cout, stride=stride, upsample=int(upsample),
                     rows_per_group=rows_per_group, alpha=alpha, post_scale=post_scale, act=act,
                     out_f32=int(out_f32), dtype=dt_code(x.dtype))
+    wbytes = int(lib().ca_conv3x3_workspace_bytes(C.byref(args)))
+    if wbytes > 0:  # split-K slabs for the small-M levels (allocator-cached, stream-ordered)
+        ws = torch.empty((wbytes,), device=x.device, dtype=torch.uint8)
+        args.workspace, args.workspace_bytes = _p(ws), wbytes
     check(lib().ca_conv3x3(C.byref(args), _stream()), "ca_conv3x3")
     return y
 

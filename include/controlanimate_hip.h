@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 1
+#define CA_ABI_VERSION 2
 
 /* element types */
 #define CA_BF16 0
@@ -127,7 +127,14 @@ typedef struct ca_conv_args {
   int32_t act;
   int32_t out_f32;
   int32_t dtype;
+  /* Scratch for the split-K schedule of small-M convolutions (8x8 / 16x16 latent levels, where
+   * M/128 x Cout/128 tiles cannot fill 256 CUs).  Caller-owned device memory of at least
+   * ca_conv3x3_workspace_bytes(args) bytes, or NULL / too small: the convolution then runs
+   * unsplit.  Results are deterministic either way (slabs are added in a fixed order). */
+  void* workspace;
+  int64_t workspace_bytes;
 } ca_conv_args;
+int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* args);
 int ca_conv3x3(const ca_conv_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------

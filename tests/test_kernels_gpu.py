@@ -154,6 +154,10 @@ CONV_CASES = [
     (16, 32, 32, 640, 320, 640, 1, False, True, False, False, 0, False),
     (16, 32, 32, 640, 0, 640, 1, True, True, False, False, 0, False),
     (16, 64, 64, 320, 0, 320, 2, False, True, False, False, 0, False),
+    # small M, long K: split-K slabs + reduce kernel (epilogue variants)
+    (32, 8, 8, 1280, 0, 1280, 1, False, True, True, True, 1, False),
+    (4, 8, 8, 640, 0, 128, 1, False, True, False, False, 0, True),
+    (8, 16, 16, 640, 640, 256, 1, False, False, False, True, 0, False),
 ]
 
 
