@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="also print the per-shape GEMM/conv table (stderr)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the ControlNet stack on the main stream (no 2nd-stream overlap)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the ControlNet+UNet part of the step from a captured hipGraph (per-kernel roofline events "
                          "are then taken in a separate eager pass after the timed region)")
@@ -253,12 +254,16 @@ def main():
     x_static = torch.empty((2 * f, hw, hw, cpad), device=device, dtype=dtype)
     t_static = torch.zeros(1, device=device, dtype=torch.float32)
     graph_state = {"graph": None, "eps": None}
+    overlap = {"on": not args.no_overlap and not args.graph}
 
     def model_eps(t):
         """ControlNet residuals + UNet3D eps for the contents of x_static at (device) timestep t."""
         down = mid = None
         if cn is not None:
-            down, mid = cn.residuals_nhwc(x_static, t, prompt, False)
+            if overlap["on"]:  # ControlNet beside the UNet encoder on a second stream (as the pipeline does)
+                down = cn.residuals_nhwc_async(x_static, t, prompt, False)
+            else:
+                down, mid = cn.residuals_nhwc(x_static, t, prompt, False)
         return unet.forward_nhwc(x_static, 2, f, t, prompt, down, mid)
 
     def step(i):
@@ -309,6 +314,7 @@ def main():
         # per step slow the step by ~7% (84 -> 90 ms); the per-kernel durations it reports agree with
         # the rocprofv3 --kernel-trace averages in profiles/.
         gr, graph_state["graph"] = graph_state["graph"], None
+        overlap["on"] = False  # one stream: a launch's event pair then times that kernel alone
         timer.enabled = True
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -343,6 +349,7 @@ def main():
         "step_algorithmic_tflop": round(step_tflop, 2),
         "step_mfma_frac": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
         "hip_graph": bool(args.graph),
+        "controlnet_second_stream": bool(not args.no_overlap and not args.graph and nets),
     }
     if not args.no_roofline:
         agg = timer.summary()

@@ -38,6 +38,7 @@ class AnimationPipelineOutput:
 
 class ControlAnimationPipeline:
     def __init__(self, vae, text_encoder, tokenizer, unet, scheduler=None):
+        self.overlap_controlnet = True  # ControlNet stack on a second HIP stream beside the UNet encoder
         if scheduler is None:  # native LCM (reference :95-101)
             scheduler = LCMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", prediction_type="epsilon")
         self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
@@ -213,7 +214,10 @@ class ControlAnimationPipeline:
             down = mid = None
             if cn is not None:
                 x_cn = x if (rep == 1 or not cn_single) else x[:f]
-                down, mid = cn.residuals_nhwc(x_cn, t, cn_prompt, guess_mode)
+                if getattr(self, "overlap_controlnet", True):
+                    down = cn.residuals_nhwc_async(x_cn, t, cn_prompt, guess_mode)  # joined inside the UNet
+                else:
+                    down, mid = cn.residuals_nhwc(x_cn, t, cn_prompt, guess_mode)
             eps = unet.forward_nhwc(x, rep, f, t, unet_prompt, down, mid, timestep_cond=w_embedding)
             coef, clip = sched.coefficients(idx)
             noise = None

@@ -89,6 +89,32 @@ class MultiControlNetResidualsPipeline:
             raise RuntimeError("call prep_control_images() first")
         return self.controlnet.forward_nhwc(x_nhwc, t, controlnet_prompt_embeds, self.prep_images, self.cond_scale, guess_mode)
 
+    def residuals_nhwc_async(self, x_nhwc: torch.Tensor, t, controlnet_prompt_embeds: torch.Tensor, guess_mode: bool):
+        """Same as residuals_nhwc, but enqueued on a second HIP stream so the ControlNet stack runs beside
+        the UNet encoder (they are independent until the residual adds, unet.py:567-586): the kernels of
+        one fill the CUs the other leaves idle in its launch tails and small-grid levels.  Returns
+        join() -> (down, mid), which makes the CALLER's current stream wait for the residuals.
+        UNet3DConditionModel.forward_nhwc accepts the join callable in place of `down_residuals`."""
+        dev = x_nhwc.device
+        main = torch.cuda.current_stream(dev)
+        side = getattr(self, "_side_stream", None)
+        if side is None or side.device != dev:
+            side = self._side_stream = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)  # x_nhwc (and on the first call the weights) were produced on `main`
+        with torch.cuda.stream(side):
+            down, mid = self.residuals_nhwc(x_nhwc, t, controlnet_prompt_embeds, guess_mode)
+            done = side.record_event()
+        x_nhwc.record_stream(side)
+
+        def join():
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(done)
+            for r in (*down, mid):
+                r.record_stream(cur)  # allocated on `side`, read on `cur`
+            return down, mid
+
+        return join
+
     @torch.no_grad()
     def __call__(self, control_model_input: torch.Tensor, t, controlnet_prompt_embeds: torch.Tensor, frame_count: int,
                  image_embeds=None, do_classifier_free_guidance=True, guess_mode=True):

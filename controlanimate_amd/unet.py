@@ -341,7 +341,8 @@ class UNet3DConditionModel(HipModelMixin, nn.Module):
     def forward_nhwc(self, x: torch.Tensor, b: int, f: int, timestep, encoder_hidden_states: torch.Tensor,
                      down_residuals=None, mid_residual=None, timestep_cond=None) -> torch.Tensor:
         """The whole forward on channels-last tensors (what the denoising loop calls directly).
-        x: [b*f, h, w, cin_pad] activation dtype; residuals: NHWC with b*f or f images (broadcast over b);
+        x: [b*f, h, w, cin_pad] activation dtype; residuals: NHWC with b*f or f images (broadcast over b),
+        or a callable returning (down, mid) that is invoked after the encoder (ControlNet on a 2nd stream);
         returns eps [b*f, h, w, out_channels] fp32."""
         device = x.device
         self._ensure_ready(device)
@@ -359,6 +360,8 @@ class UNet3DConditionModel(HipModelMixin, nn.Module):
         for blk in self.down_blocks:
             x, outs = blk(x, ctx)
             skips += outs
+        if callable(down_residuals):  # MultiControlNetResidualsPipeline.residuals_nhwc_async: join the side stream
+            down_residuals, mid_residual = down_residuals()
         if down_residuals is not None:
             if len(down_residuals) != len(skips):
                 raise ValueError("expected %d ControlNet residuals" % len(skips))
