@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="also print the per-shape GEMM/conv table (stderr)")
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing (reported beside the metric)")
     ap.add_argument("--no-overlap", action="store_true", help="run the ControlNet stack on the main stream (no 2nd-stream overlap)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the ControlNet+UNet part of the step from a captured hipGraph (per-kernel roofline events "
@@ -211,6 +212,28 @@ def cpu_baseline(threads: int):
                       "config-2 step is 44.6 TFLOP => FLOP-scaled estimate %.1f s/step" % (dt * 44.6 / 4.09)}
 
 
+def time_vae(args, device, dtype):
+    """ms per window for encoding / decoding all frames with the HIP AutoencoderKL."""
+    from controlanimate_amd.vae import AutoencoderKL
+    torch.manual_seed(0)
+    vae = AutoencoderKL.from_config().to(device).prepare(device, dtype)
+    g = torch.Generator().manual_seed(4321)
+    imgs = (torch.rand(args.frames, 3, args.size, args.size, generator=g) * 2 - 1).to(device)
+    lat = torch.randn(args.frames, 4, args.size // 8, args.size // 8, generator=g).to(device)
+    out = {}
+    for name, fn in (("encode_ms_per_window", lambda: vae.encode_moments(imgs)), ("decode_ms_per_window", lambda: vae.decode(lat))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+    del vae
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     from controlanimate_amd import kernels as K
@@ -324,6 +347,9 @@ def main():
         roof_elapsed = time.perf_counter() - t1
         timer.enabled = False
         graph_state["graph"] = gr
+    vae_ms = None
+    if not args.no_vae and rank == 0:
+        vae_ms = time_vae(args, device, dtype)
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -348,6 +374,11 @@ def main():
                    "weight_broadcast_bytes": bytes_bcast},
         "step_algorithmic_tflop": round(step_tflop, 2),
         "step_mfma_frac": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
+        "vae": None if vae_ms is None else {
+            **vae_ms,
+            "frames_per_sec_end_to_end": round(world * f / (STEPS_PER_WINDOW * sec_per_step + 1e-3 * (vae_ms["encode_ms_per_window"] + vae_ms["decode_ms_per_window"])), 4),
+            "note": "SD1.5 AutoencoderKL on the same kernels, random weights; encode + decode of all frames of one window "
+                    "(brackets the 20 denoise steps; not part of `value`)"},
         "hip_graph": bool(args.graph),
         "controlnet_second_stream": bool(not args.no_overlap and not args.graph and nets),
     }

@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
         ("stride", C.c_int32), ("upsample", C.c_int32), ("rows_per_group", C.c_int32),
         ("alpha", C.c_float), ("post_scale", C.c_float),
         ("act", C.c_int32), ("out_f32", C.c_int32), ("dtype", C.c_int32),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("pad_asym", C.c_int32),
     ]
 
 
@@ -93,6 +93,7 @@ SYMBOLS = {
     "ca_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "ca_conv3x3": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "ca_conv3x3_workspace_bytes": (C.c_int64, [C.POINTER(ConvArgs)]),
+    "ca_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_float, C.c_int32, C.c_void_p]),
     "ca_groupnorm_partials_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ca_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),
     "ca_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),

@@ -8,7 +8,7 @@ Call surface of the reference's animatediff/pipelines/controlanimation_pipeline.
              CFG combine + scheduler update, ONE fused kernel (:844-849 / :833)
   skipped    torch.cuda.empty_cache() every step (:794) -- allocator flush + sync, no output effect.
 
-Out of scope in this round (SURVEY 8f "next"): VAE encode/decode and the CLIP text encoder.  The
+The VAE is controlanimate_amd/vae.py; the CLIP text encoder stays out of scope.  The
 pipeline therefore takes `prompt_embeds` / `negative_prompt_embeds` (as the reference's facade
 already does, modules/controlanimate_pipeline.py:133-146); if a `vae` object with the diffusers
 AutoencoderKL interface is supplied it is used for encode/decode exactly where the reference does,
@@ -49,7 +49,8 @@ class ControlAnimationPipeline:
 
     def to(self, device):
         self.device = torch.device(device)
-        self.unet.to(self.device)
+        if self.unet is not None:
+            self.unet.to(self.device)
         if hasattr(self.vae, "to"):
             self.vae.to(self.device)
         return self
@@ -74,6 +75,16 @@ class ControlAnimationPipeline:
         if self.vae is None:
             raise RuntimeError("frames given as images need a `vae` (VAE encode is a 'next' component); pass latents instead")
         out = []
+        if hasattr(self.vae, "encode_moments") and len(frames) > 0:
+            # HIP VAE: one batched encoder pass for all frames; the Gaussian sample is still drawn frame by
+            # frame from the same generator, i.e. the reference's RNG consumption (:577, :589)
+            from .vae import DiagonalGaussianDistribution
+            imgs = torch.stack([_image_to_chw01(fr) * 2.0 - 1.0 for fr in frames]).to(self.device)
+            mean, logvar = self.vae.encode_moments(imgs)
+            for i in range(len(frames)):
+                lat = DiagonalGaussianDistribution(mean[i:i + 1], logvar[i:i + 1]).sample(generator)
+                out.append(self.vae.config.scaling_factor * lat.float())
+            return out
         for fr in frames:
             img = (_image_to_chw01(fr) * 2.0 - 1.0)[None].to(self.device)
             lat = self.vae.encode(img).latent_dist.sample(generator)
@@ -121,8 +132,14 @@ class ControlAnimationPipeline:
             raise RuntimeError("no vae attached: request output_type='latent'")
         video_length = latents.shape[2]
         latents = 1 / self.vae.config.scaling_factor * latents
-        frames = [self.vae.decode(latents[:, :, i]).sample for i in range(video_length)]
-        video = torch.stack(frames, dim=2)
+        if hasattr(self.vae, "encode_moments"):  # HIP VAE: all frames of the window in one batch (no cross-frame op)
+            b, c, f, h, w = latents.shape
+            flat = latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+            video = self.vae.decode(flat).sample
+            video = video.view(b, f, *video.shape[1:]).permute(0, 2, 1, 3, 4)
+        else:
+            frames = [self.vae.decode(latents[:, :, i]).sample for i in range(video_length)]
+            video = torch.stack(frames, dim=2)
         return (video / 2 + 0.5).clamp(0, 1).cpu().float().numpy()
 
     # ------------------------------------------------------------------------------------------

@@ -159,6 +159,61 @@ extern "C" int ca_add_bcast(const void* a, const void* b, void* out, int64_t n, 
   return CA_OK;
 }
 
+// Row softmax of an fp32 score matrix into the activation dtype: the VAE's single-head, head_dim 512
+// attention (diffusers AutoencoderKL mid block) runs as GEMM (scores, fp32) -> this -> GEMM (P V);
+// one block per row, three passes over a row that stays in L2.
+namespace {
+template <int DT>
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* x, u16* y, int cols, int64_t ldx, int64_t ldy, float scale_log2) {
+  __shared__ float red[4];
+  const float* xr = x + (int64_t)blockIdx.x * ldx;
+  u16* yr = y + (int64_t)blockIdx.x * ldy;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float m = -INFINITY;
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    m = fmaxf(fmaxf(fmaxf(m, v[0]), fmaxf(v[1], v[2])), v[3]);
+  }
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red[wid] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  const float nm = -m * scale_log2;
+  float sum = 0.f;
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sum += __builtin_amdgcn_exp2f(fmaf(v[k], scale_log2, nm));
+  }
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) red[wid] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    u32x2 o;
+    o[0] = pack2<DT>(__builtin_amdgcn_exp2f(fmaf(v[0], scale_log2, nm)) * inv, __builtin_amdgcn_exp2f(fmaf(v[1], scale_log2, nm)) * inv);
+    o[1] = pack2<DT>(__builtin_amdgcn_exp2f(fmaf(v[2], scale_log2, nm)) * inv, __builtin_amdgcn_exp2f(fmaf(v[3], scale_log2, nm)) * inv);
+    *reinterpret_cast<u32x2*>(yr + c) = o;
+  }
+}
+}  // namespace
+
+extern "C" int ca_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy, float scale,
+                               int32_t dtype, void* stream) {
+  CA_REQUIRE(x && y, "ca_softmax_rows: null operand");
+  CA_REQUIRE(rows > 0 && rows < (1ll << 31) && cols > 0 && cols % 4 == 0, "ca_softmax_rows: rows=%lld cols=%d (cols %% 4)", (long long)rows, cols);
+  CA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= cols && ldy >= cols, "ca_softmax_rows: leading dimensions");
+  CA_REQUIRE(dtype == CA_BF16 || dtype == CA_F16, "ca_softmax_rows: dtype %d", dtype);
+  const float sl2 = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CA_BF16) hipLaunchKernelGGL(k_softmax_rows<CA_BF16>, dim3((unsigned)rows), dim3(256), 0, st, x, (u16*)y, cols, ldx, ldy, sl2);
+  else hipLaunchKernelGGL(k_softmax_rows<CA_F16>, dim3((unsigned)rows), dim3(256), 0, st, x, (u16*)y, cols, ldx, ldy, sl2);
+  CA_CHECK_LAUNCH("ca_softmax_rows");
+  return CA_OK;
+}
+
 extern "C" int ca_silu_f32(const float* x, float* y, int64_t n, void* stream) {
   CA_REQUIRE(x && y && n > 0, "ca_silu_f32: bad args");
   hipLaunchKernelGGL(k_silu_f32, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, y, n);

@@ -39,7 +39,7 @@ struct GemmKParams {
   int taps;        // 1 (dense) or 9 (3x3)
   int kc_tiles;    // ceil((c1+c2)/64)
   // conv geometry
-  int hin, win, hout, wout, stride, ups;
+  int hin, win, hout, wout, stride, ups, pad_lo;  // pad_lo: zero rows/cols before the image (after: implicit)
   int rows_per_group;
   float alpha, post;
   int act, geglu, out_f32;
@@ -308,8 +308,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmKParams p) {
       int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        int hi = a_ho[i] * p.stride + kh - 1;
-        int wi = a_wo[i] * p.stride + kw - 1;
+        int hi = a_ho[i] * p.stride + kh - p.pad_lo;
+        int wi = a_wo[i] * p.stride + kw - p.pad_lo;
         bool ok = cok && a_ok[i] && hi >= 0 && wi >= 0 && hi < (p.hin << p.ups) && wi < (p.win << p.ups);
         int hs = hi >> p.ups, ws = wi >> p.ups;
         int64_t pix = ((int64_t)a_img[i] * p.hin + hs) * p.win + ws;
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_g
       const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
       for (int i = 0; i < AG; ++i) {
-        const int hi = a_ho[i] * p.stride + kh - 1;
-        const int wi = a_wo[i] * p.stride + kw - 1;
+        const int hi = a_ho[i] * p.stride + kh - p.pad_lo;
+        const int wi = a_wo[i] * p.stride + kw - p.pad_lo;
         const bool ok = a_ok[i] && hi >= 0 && wi >= 0 && hi < (p.hin << p.ups) && wi < (p.win << p.ups);
         const int pix = (a_img[i] * p.hin + (hi >> p.ups)) * p.win + (wi >> p.ups);
         const unsigned off = ok ? ((unsigned)pix * (unsigned)cs + (unsigned)(cbase + a_chunk[i] * 8)) * 2u : DMA_OOB;
@@ -754,7 +754,8 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
 extern "C" int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* a) {
   if (!a || a->images <= 0 || a->hin <= 0 || a->win <= 0 || (a->stride != 1 && a->stride != 2)) return 0;
   const int hl = a->hin << a->upsample, wl = a->win << a->upsample;
-  const int64_t m = (int64_t)a->images * ((hl + 2 - 3) / a->stride + 1) * ((wl + 2 - 3) / a->stride + 1);
+  const int pad = a->pad_asym ? 1 : 2;
+  const int64_t m = (int64_t)a->images * ((hl + pad - 3) / a->stride + 1) * ((wl + pad - 3) / a->stride + 1);
   const int kc = a->cin1 + a->cin2;
   if (m >= (1ll << 31) || kc % BK != 0 || (a->cin2 != 0 && a->cin1 % BK != 0)) return 0;
   const int s = splitk_plan((int)m, a->cout, 9 * ceil_div_i(kc, BK), 0);
@@ -775,8 +776,10 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
   int rc = check_epilogue("ca_conv3x3", a->cout, 0, a->out_f32, a->cout, a->ld_res, a->residual);
   if (rc) return rc;
   const int hl = a->hin << a->upsample, wl = a->win << a->upsample;
-  const int hout = (hl + 2 - 3) / a->stride + 1;
-  const int wout = (wl + 2 - 3) / a->stride + 1;
+  CA_REQUIRE(a->pad_asym == 0 || a->pad_asym == 1, "ca_conv3x3: pad_asym %d", a->pad_asym);
+  const int pad = a->pad_asym ? 1 : 2;  // total padding per axis: 1+1, or 0 before / 1 after
+  const int hout = (hl + pad - 3) / a->stride + 1;
+  const int wout = (wl + pad - 3) / a->stride + 1;
   const int64_t m64 = (int64_t)a->images * hout * wout;
   CA_REQUIRE(m64 < (1ll << 31), "ca_conv3x3: too many output pixels");
   GemmKParams p{};
@@ -805,6 +808,7 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
   p.wout = wout;
   p.stride = a->stride;
   p.ups = a->upsample;
+  p.pad_lo = a->pad_asym ? 0 : 1;
   p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
   p.alpha = a->alpha;
   p.post = a->post_scale;

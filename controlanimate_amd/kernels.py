@@ -79,8 +79,9 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
             bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
             rows_per_group: int = 0, residual: Optional[torch.Tensor] = None, stride: int = 1,
             upsample: bool = False, alpha: float = 1.0, post_scale: float = 1.0, act: int = ACT_NONE,
-            out_f32: bool = False) -> torch.Tensor:
-    """x: [images, H, W, Cin1] (+x2 [.., Cin2]); w: [Cout, 3, 3, Cin1+Cin2]; returns NHWC."""
+            out_f32: bool = False, pad_asym: bool = False) -> torch.Tensor:
+    """x: [images, H, W, Cin1] (+x2 [.., Cin2]); w: [Cout, 3, 3, Cin1+Cin2]; returns NHWC.
+    pad_asym: pad (0 before, 1 after) instead of 1/1 -- diffusers Downsample2D(padding=0)."""
     _req_cuda(x, w, x2, bias, rowbias, residual)
     assert x.dim() == 4 and x.is_contiguous() and w.dim() == 4 and w.is_contiguous()
     images, hin, win, cin1 = x.shape
@@ -91,7 +92,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
     cout = w.shape[0]
     assert tuple(w.shape[1:]) == (3, 3, cin1 + cin2) and w.dtype == x.dtype
     hl, wl = (hin * 2, win * 2) if upsample else (hin, win)
-    hout, wout = (hl - 1) // stride + 1, (wl - 1) // stride + 1
+    pad = 1 if pad_asym else 2
+    hout, wout = (hl + pad - 3) // stride + 1, (wl + pad - 3) // stride + 1
     y = torch.empty((images, hout, wout, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     ld_res = 0
     if residual is not None:
@@ -106,7 +108,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
                     ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, images=images, hin=hin,
                     win=win, cin1=cin1, cin2=cin2, cout=cout, stride=stride, upsample=int(upsample),
                     rows_per_group=rows_per_group, alpha=alpha, post_scale=post_scale, act=act,
-                    out_f32=int(out_f32), dtype=dt_code(x.dtype))
+                    out_f32=int(out_f32), dtype=dt_code(x.dtype), pad_asym=int(pad_asym))
     wbytes = int(lib().ca_conv3x3_workspace_bytes(C.byref(args)))
     if wbytes > 0:  # split-K slabs for the small-M levels (allocator-cached, stream-ordered)
         ws = torch.empty((wbytes,), device=x.device, dtype=torch.uint8)
@@ -227,6 +229,16 @@ def add_bcast(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = No
     check(lib().ca_add_bcast(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), b.numel(), dt_code(a.dtype),
                              _stream()), "ca_add_bcast")
     return out
+
+
+def softmax_rows(x: torch.Tensor, dtype: torch.dtype, scale: float = 1.0) -> torch.Tensor:
+    """Row softmax of an fp32 [rows, cols] score matrix (last dim contiguous), output in `dtype`."""
+    _req_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    y = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(lib().ca_softmax_rows(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], x.stride(0), y.stride(0), float(scale),
+                                dt_code(dtype), _stream()), "ca_softmax_rows")
+    return y
 
 
 def silu_f32(x: torch.Tensor) -> torch.Tensor:

@@ -133,6 +133,10 @@ typedef struct ca_conv_args {
    * unsplit.  Results are deterministic either way (slabs are added in a fixed order). */
   void* workspace;
   int64_t workspace_bytes;
+  /* 0: zero padding 1 on every side (Conv2d padding=1).  1: no padding before, one row/column after
+   * (diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + Conv2d(stride=2), the VAE encoder's
+   * downsamplers): Hout = (H + 1 - 3) / stride + 1. */
+  int32_t pad_asym;
 } ca_conv_args;
 int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* args);
 int ca_conv3x3(const ca_conv_args* args, void* stream);
@@ -236,6 +240,14 @@ int ca_attention(const ca_attn_args* args, void* stream);
  * b=1 residuals over the CFG batch (animatediff/models/unet.py:567-576,584-585). n multiple of 8. */
 int ca_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t b_period,
                  int32_t dtype, void* stream);
+
+/* y[r, :] = softmax(scale * x[r, :]) for an fp32 score matrix, written in `dtype`.
+ * Replaces the softmax inside F.scaled_dot_product_attention for the VAE's mid-block attention
+ * (third-party diffusers==0.23.0 AutoencoderKL: Attention(heads=1, dim_head=512) called at
+ * animatediff/pipelines/controlanimation_pipeline.py:508 (decode) and :577,589 (encode)), whose
+ * head_dim is beyond ca_attention's fused kernel: scores and P.V run through ca_gemm. cols % 4 == 0. */
+int ca_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy,
+                    float scale, int32_t dtype, void* stream);
 
 /* y = silu(x) on fp32 vectors (ResnetBlock3D: time_emb_proj(silu(temb)), resnet.py:196). */
 int ca_silu_f32(const float* x, float* y, int64_t n, void* stream);

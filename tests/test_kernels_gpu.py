@@ -196,6 +196,33 @@ def test_conv3x3(case, dtype):
     close(out, ref, dtype, f"conv{case}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128), (3, 10, 6, 32, 32), (2, 64, 64, 128, 128)])
+def test_conv3x3_asymmetric_pad_stride2(case, dtype):
+    """diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + Conv2d(3, stride=2) (VAE encoder)."""
+    k = _k()
+    images, h, w_, cin, cout = case
+    x = rnd(images, h, w_, cin, dtype=dtype, seed=21)
+    wt = rnd(cout, cin, 3, 3, dtype=dtype, scale=(9 * cin) ** -0.5, seed=22)
+    bias = rnd(cout, dtype=torch.float32, seed=23)
+    ref = F.conv2d(F.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1)), wt.float(), bias, stride=2, padding=0).permute(0, 2, 3, 1)
+    out = k.conv3x3(x.to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), bias=bias.to(DEV), stride=2, pad_asym=True)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, f"conv_asym{case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(7, 64), (300, 4096), (16, 1000)])
+def test_softmax_rows(rows, cols, dtype):
+    k = _k()
+    x = rnd(rows, cols, dtype=torch.float32, scale=4.0, seed=31)
+    ref = torch.softmax(x * 0.37, -1)
+    out = k.softmax_rows(x.to(DEV), dtype, 0.37)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, f"softmax_rows({rows},{cols})")
+    assert (out.float().sum(-1).cpu() - 1).abs().max() < (2e-2 if dtype == torch.bfloat16 else 4e-3)
+
+
 # ------------------------------------------------------------------------------------ norms
 GN_CASES = [
     # images, h, w, c1, c2, frames_per_stat, act, eps
