@@ -1,0 +1,187 @@
+"""Host window orchestrator: the sliding-window loop of scripts/vid2vid.py:165-262
+around `ControlAnimatePipeline.animate`, without ffmpeg / OmegaConf / the upscaler (frames come from and
+go to any iterable / callable; the reference pipes raw RGB through ffmpeg, :93-136, :259-260).
+
+Per window (file:line of the reference behaviour mirrored):
+  :168-175  batch = the previous window's last `overlap_length` INPUT frames + (frame_count - overlaps) new ones
+  :189-192  with overlaps: strength := overlap_strength; loop_back_frames feeds the previous OUTPUT frames back in
+  :197-213  optional initial IP-Adapter round (run once, then re-run on its own last frames)
+  :215-221  colour match every frame to `last_output_frame` (third-party color_matcher 'hm-mkl-hm' in the
+            reference; here a callable hook, default = per-channel mean/std transfer, see match_colors_meanstd)
+  :221      last_output_frame = frames[overlap_length - 1]   (index -1, the last frame, when overlap_length == 0)
+  :223-224  last_output_frames = frames[-overlap_length:]     (IP-Adapter image prompt / latent init of the next window)
+  :226-228  cross-fade: frames[i] = blend(frames[i], previous_overlap_output[i], (n - i - 0.5) / n)
+  :230-232  carry the blended tail and the matching input frames to the next window
+  :235      emit len(batch) - overlaps frames, or the whole batch once the requested frame count is reached
+
+Multi-GPU: with overlap_strength >= 1 and no IP-Adapter a window's denoising does not depend on
+its predecessor's pixels, so windows can be denoised on different ranks (window_shard.windows_for_rank)
+and only this host-side blend / colour-match pass runs in window order on rank 0: `blend_windows`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Iterable, Iterator, List, Optional, Sequence
+
+import numpy as np
+
+try:  # PIL is what the reference's frames are; numpy HxWx3 uint8 arrays are accepted everywhere too
+    from PIL import Image
+except Exception:  # pragma: no cover
+    Image = None
+
+
+def _to_np(frame) -> np.ndarray:
+    return np.asarray(frame)
+
+
+def _like(arr: np.ndarray, proto):
+    if Image is not None and not isinstance(proto, np.ndarray):
+        return Image.fromarray(arr)
+    return arr
+
+
+def blend(a, b, alpha: float):
+    """PIL.Image.blend semantics: a * (1 - alpha) + b * alpha, uint8 result of the type of `a`."""
+    if Image is not None and not isinstance(a, np.ndarray) and not isinstance(b, np.ndarray):
+        return Image.blend(a, b, alpha)
+    x, y = _to_np(a).astype(np.float32), _to_np(b).astype(np.float32)
+    out = x * (1.0 - alpha) + y * alpha
+    return _like(np.clip(out, 0, 255).astype(np.uint8), a)  # PIL truncates
+
+
+def match_colors_meanstd(frames: Sequence, ref_frame) -> List:
+    """Default colour-match hook: per-channel mean/std transfer to `ref_frame` (Reinhard).  The reference
+    calls the third-party color_matcher package ('hm-mkl-hm', modules/utils.py:116-130), which is absent
+    here; pass that as `match_colors=` to reproduce it exactly."""
+    ref = _to_np(ref_frame).astype(np.float32)
+    rm, rs = ref.reshape(-1, ref.shape[-1]).mean(0), ref.reshape(-1, ref.shape[-1]).std(0) + 1e-6
+    out = []
+    for fr in frames:
+        x = _to_np(fr).astype(np.float32)
+        m, s = x.reshape(-1, x.shape[-1]).mean(0), x.reshape(-1, x.shape[-1]).std(0) + 1e-6
+        y = (x - m) / s * rs + rm
+        out.append(_like(np.clip(y + 0.5, 0, 255).astype(np.uint8), fr))
+    return out
+
+
+@dataclass
+class WindowConfig:
+    """The per-window settings vid2vid.py writes into `config` before calling animate (:176-196)."""
+    frame_count: int = 16
+    overlap_length: int = 8
+    strength: float = 1.0
+    overlap_strength: float = 0.85
+    loop_back_frames: bool = True
+    do_initial_generation: bool = False
+    # filled in per window
+    overlap: bool = False
+    overlaps: int = 0
+    epoch: int = 0
+    L: int = 0
+    extra: dict = field(default_factory=dict)
+
+
+AnimateFn = Callable[[List, Optional[List], WindowConfig], List]
+
+
+def run_windows(input_frames: Optional[Iterable], animate: AnimateFn, cfg: WindowConfig, total_frames: Optional[int] = None,
+                match_colors: Optional[Callable[[Sequence, object], List]] = match_colors_meanstd) -> Iterator[List]:
+    """Yields the output frames of each window, in order (what the reference writes to the encoder).
+    input_frames: iterable of frames (vid2vid) or None (text-to-video: `total_frames` must be given and the
+    batches are lists of None of the window length).  `animate(batch, last_output_frames, cfg)` is
+    ControlAnimatePipeline.animate's contract (modules/controlanimate_pipeline.py:124-170)."""
+    src = iter(input_frames) if input_frames is not None else None
+    if src is None and total_frames is None:
+        raise ValueError("text-to-video needs total_frames")
+    base_strength = cfg.strength
+    frame_count_cfg = cfg.frame_count
+    overlap_frames: List = []
+    overlap_inputs: List = []
+    last_output_frames = None
+    last_output_frame = None
+    initial_done = not cfg.do_initial_generation
+    emitted, epoch = 0, 0
+    exhausted = False
+    pending: List = []  # one frame of look-ahead: a stream's last window must be known when it is emitted
+
+    def pull():
+        if pending:
+            return pending.pop()
+        return next(src)
+
+    # the reference counts written frames from 1 (:139) and stops once the count reaches the requested total
+    while not exhausted and (total_frames is None or emitted + 1 < total_frames):
+        batch: List = list(overlap_inputs)
+        want = frame_count_cfg - len(overlap_frames)
+        if src is not None:
+            try:
+                for _ in range(want):
+                    batch.append(pull())
+                pending.append(pull())
+            except StopIteration:
+                exhausted = True
+            if len(batch) == len(overlap_inputs):  # no new frame arrived
+                break
+        else:
+            batch += [None] * want
+        cfg.overlap, cfg.overlaps = len(overlap_frames) > 0, len(overlap_frames)
+        cfg.L = cfg.frame_count = len(batch)
+        cfg.strength = base_strength
+        if overlap_frames:
+            cfg.strength = cfg.overlap_strength
+            if cfg.loop_back_frames:
+                batch[:len(overlap_frames)] = overlap_frames
+        cfg.epoch = epoch
+        epoch += 1
+        if not initial_done:
+            frames = animate(batch, last_output_frames, cfg)
+            last_output_frame = frames[0]
+            cfg.strength = cfg.overlap_strength
+            cfg.overlaps = len(frames[-cfg.overlap_length:])
+            frames = animate(batch, list(frames[-cfg.overlap_length:]), cfg)
+            initial_done = True
+        else:
+            frames = animate(batch, last_output_frames, cfg)
+        frames = list(frames)
+        if last_output_frame is not None and match_colors is not None:
+            frames = list(match_colors(frames, last_output_frame))
+        last_output_frame = frames[max(cfg.overlap_length - 1, -1)]
+        if cfg.overlap_length > 0:
+            last_output_frames = frames[-cfg.overlap_length:]
+        n = len(overlap_frames)
+        for i, prev in enumerate(overlap_frames):
+            frames[i] = blend(frames[i], prev, (n - i - 0.5) / n)
+        if cfg.overlap_length > 0:
+            overlap_frames = frames[-cfg.overlap_length:]
+            overlap_inputs = batch[-cfg.overlap_length:]
+        last = exhausted or (total_frames is not None and emitted + 1 + len(batch) >= total_frames)  # (:235)
+        out_n = len(batch) if last else len(batch) - len(overlap_frames)
+        emitted += out_n
+        yield frames[:out_n]
+        if last:
+            break
+    cfg.frame_count = frame_count_cfg
+
+
+def blend_windows(windows: Sequence[Sequence], overlap_length: int,
+                  match_colors: Optional[Callable[[Sequence, object], List]] = None) -> List:
+    """Rank-0 pass of the window-sharded mode: `windows[k]` are the frames window k produced on some GPU
+    (each window re-generated its first `overlap_length` frames); colour-match and cross-fade in window
+    order exactly as the sequential loop does and return the final frame list."""
+    out: List = []
+    overlap_frames: List = []
+    last_output_frame = None
+    for k, frames in enumerate(windows):
+        frames = list(frames)
+        if last_output_frame is not None and match_colors is not None:
+            frames = list(match_colors(frames, last_output_frame))
+        last_output_frame = frames[max(overlap_length - 1, -1)]
+        n = len(overlap_frames)
+        for i, prev in enumerate(overlap_frames):
+            frames[i] = blend(frames[i], prev, (n - i - 0.5) / n)
+        if overlap_length > 0:
+            overlap_frames = frames[-overlap_length:]
+        is_last = k == len(windows) - 1
+        out += frames if is_last else frames[:len(frames) - len(overlap_frames)]
+    return out

@@ -1,0 +1,98 @@
+"""Host window orchestrator (controlanimate_amd/vid2vid.py) against a hand-worked run of the loop in
+scripts/vid2vid.py:165-262 (frame_count 4, overlap_length 2, 8 input frames)."""
+import numpy as np
+from PIL import Image
+
+
+def gray(v):
+    return Image.fromarray(np.full((4, 4, 3), v, np.uint8))
+
+
+def val(img):
+    return int(np.asarray(img)[0, 0, 0])
+
+
+def test_sequential_loop_matches_hand_worked_example():
+    from controlanimate_amd.vid2vid import WindowConfig, run_windows
+    calls = []
+
+    def animate(batch, last_output_frames, cfg):
+        calls.append(dict(inputs=[val(b) for b in batch], last=None if last_output_frames is None else [val(x) for x in last_output_frames],
+                          strength=cfg.strength, overlaps=cfg.overlaps, epoch=cfg.epoch, L=cfg.L))
+        return [gray(val(b) + 10 * cfg.epoch) for b in batch]
+
+    cfg = WindowConfig(frame_count=4, overlap_length=2, strength=1.0, overlap_strength=0.6, loop_back_frames=True)
+    out = [[val(f) for f in w] for w in run_windows([gray(i) for i in range(8)], animate, cfg, match_colors=None)]
+    # window 0: inputs 0..3 -> outputs 0..3; emits 2, carries outputs [2,3] + inputs [2,3]
+    # window 1: inputs = fed-back outputs [2,3] + new [4,5] -> [12,13,14,15]; cross-fade with [2,3] at 0.75 / 0.25
+    #           -> [12*.25+2*.75, 13*.75+3*.25] = [4.5, 10.5] -> PIL truncates to [4, 10]; carries [14, 15]
+    # window 2: inputs = [14,15] + [6,7] -> +20 -> [34,35,26,27]; fade with [14,15]: [34*.25+14*.75, 35*.75+15*.25] = [19, 30];
+    #           the stream ends here, so the whole window is emitted
+    assert out == [[0, 1], [4, 10], [19, 30, 26, 27]]
+    assert [c["inputs"] for c in calls] == [[0, 1, 2, 3], [2, 3, 4, 5], [14, 15, 6, 7]]
+    assert [c["last"] for c in calls] == [None, [2, 3], [14, 15]]
+    assert [c["strength"] for c in calls] == [1.0, 0.6, 0.6] and [c["overlaps"] for c in calls] == [0, 2, 2]
+    assert [c["epoch"] for c in calls] == [0, 1, 2] and all(c["L"] == 4 for c in calls)
+
+
+def test_no_loop_back_refeeds_input_frames_and_total_frames_cutoff():
+    from controlanimate_amd.vid2vid import WindowConfig, run_windows
+    seen = []
+
+    def animate(batch, last, cfg):
+        seen.append([val(b) for b in batch])
+        return [gray(val(b) + 100) for b in batch]
+
+    cfg = WindowConfig(frame_count=4, overlap_length=2, loop_back_frames=False)
+    out = list(run_windows((gray(i) for i in range(100)), animate, cfg, total_frames=6, match_colors=None))
+    # the reference's written-frame counter starts at 1 (:139): 1 + 4 < 6 -> 2 frames; 3 + 4 >= 6 -> the whole window
+    assert seen == [[0, 1, 2, 3], [2, 3, 4, 5]]
+    assert [len(w) for w in out] == [2, 4]
+
+
+def test_colour_match_reference_frame_and_text_to_video():
+    from controlanimate_amd.vid2vid import WindowConfig, run_windows
+    refs = []
+
+    def mc(frames, ref):
+        refs.append(val(ref))
+        return list(frames)
+
+    def animate(batch, last, cfg):
+        return [gray(10 * cfg.epoch + i) for i in range(len(batch))]
+
+    cfg = WindowConfig(frame_count=4, overlap_length=2)
+    out = list(run_windows(None, animate, cfg, total_frames=6, match_colors=mc))
+    # last_output_frame = frames[overlap_length - 1] AFTER colour matching, BEFORE the cross-fade (:221)
+    assert refs == [1] and [len(w) for w in out] == [2, 4]
+    cfg0 = WindowConfig(frame_count=3, overlap_length=0)
+    refs.clear()
+    out0 = list(run_windows(None, animate, cfg0, total_frames=6, match_colors=mc))
+    assert refs == [2] and [len(w) for w in out0] == [3, 3]  # overlap 0: the reference frame is the last one (index -1)
+
+
+def test_blend_windows_equals_sequential_for_independent_windows():
+    from controlanimate_amd.vid2vid import WindowConfig, blend_windows, match_colors_meanstd, run_windows
+    rng = np.random.default_rng(0)
+    inputs = [Image.fromarray(rng.integers(0, 255, (8, 8, 3), dtype=np.uint8)) for _ in range(10)]
+
+    def animate(batch, last, cfg):  # depends on its input frames only (overlap_strength >= 1, no IP-Adapter)
+        return [Image.fromarray(255 - np.asarray(b)) for b in batch]
+
+    cfg = WindowConfig(frame_count=4, overlap_length=2, loop_back_frames=False)
+    seq = [f for w in run_windows(inputs, animate, cfg, match_colors=match_colors_meanstd) for f in w]
+    from controlanimate_amd.window_shard import window_plan
+    plan = window_plan(len(inputs), 4, 2)
+    wins = [animate(inputs[a:b], None, cfg) for a, b in plan]          # any rank, any order
+    par = blend_windows(wins, 2, match_colors=match_colors_meanstd)
+    assert len(par) == len(seq) == 10
+    assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(par, seq))
+
+
+def test_meanstd_match_moves_statistics():
+    from controlanimate_amd.vid2vid import match_colors_meanstd
+    rng = np.random.default_rng(1)
+    ref = rng.normal(100, 10, (16, 16, 3)).clip(0, 255).astype(np.uint8)
+    src = rng.normal(150, 30, (16, 16, 3)).clip(0, 255).astype(np.uint8)
+    out = np.asarray(match_colors_meanstd([src], ref)[0]).astype(np.float32)
+    assert abs(out.mean() - ref.mean()) < 1.5 and abs(out.std() - ref.std()) < 1.5
