@@ -143,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmKParams& p, f32x4
 // at this point (the loop ends with a barrier).  Staged value = (acc + bias + rowbias) * alpha
 // rounded to the activation type; the residual is added in fp32 afterwards (the reference's fp16
 // pipeline rounds at the same place: linear output, then `+ hidden_states`).
-template <int DT, int BM, int BN, int TM, int TN>
+template <int DT, int BM, int BN, int TM, int TN, int NT = 256>
 __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)[TM][TN], u16* cs, int m0, int n0, int wm, int wn,
                                               int l15, int g, int tid) {
   if (p.n < 8) {  // conv_out (Cout = 4)
@@ -184,8 +184,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
   __syncthreads();
   constexpr int CH = BN / 8;
 #pragma unroll
-  for (int u = 0; u < BM * CH / 256; ++u) {
-    const int id = tid + u * 256;
+  for (int u = 0; u < BM * CH / NT; ++u) {
+    const int id = tid + u * NT;
     const int row = id / CH, c8 = id - row * CH;
     const int m = m0 + row, n = n0 + c8 * 8;
     if (m >= p.m || n >= p.n) continue;
@@ -377,11 +377,13 @@ constexpr unsigned DMA_OOB = 0xFFFFFFF0u;  // beyond any descriptor size we acce
 //           then a raw s_barrier: DMA transfers stay in flight across barriers
 //           (cdna_hip_programming.md "Pipelining across barriers").  All LDS is one array.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF>
-__global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_gemm_dma(GemmKParams p) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2) * 4 / (WAVES_M * WAVES_N))
+void k_gemm_dma(GemmKParams p) {
+  constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;  // 4 waves (128-row tiles) or 8 waves (256x128 tiles)
   constexpr int TM = BM / WAVES_M / 16;
   constexpr int TN = BN / WAVES_N / 16;
-  constexpr int AG = BM / 32;  // 8-row groups staged per wave (A)
-  constexpr int BG = BN / 32;  // (W)
+  constexpr int AG = BM / 8 / NW;  // 8-row groups staged per wave (A)
+  constexpr int BG = BN / 8 / NW;  // (W)
   // the LDS-staged epilogue needs BM x (BN + 8) elements: more than ONE 128x128x64 stage
   constexpr int SMEM_ELEMS = NBUF * (BM + BN) * BK > BM * (BN + 8) ? NBUF * (BM + BN) * BK : BM * (BN + 8);
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_ELEMS];
@@ -528,26 +530,6 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_g
       compute(buf);
       __syncthreads();
     }
-  } else {
-    // NBUF-slot ring, tiles issued NBUF-1 ahead.  Before computing tile t a wave waits until at most
-    // the transfers of the (up to NBUF-2) younger tiles are outstanding, then a raw barrier.
-    constexpr int PER_TILE = AG + BG;  // LDS-DMA instructions per wave per tile
-#pragma unroll
-    for (int i = 0; i < NBUF - 1; ++i)
-      if (i < nt) stage(t_first + i, i);
-    int buf = 0;
-    for (int t = 0; t < nt; ++t) {
-      const int younger = nt - 1 - t < NBUF - 2 ? nt - 1 - t : NBUF - 2;
-      if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER_TILE) : "memory");
-      __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; tile t-1 is no longer read
-      if (t + NBUF - 1 < nt) stage(t_first + t + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
-      compute(buf);
-      buf = buf == NBUF - 1 ? 0 : buf + 1;
-    }
-    __builtin_amdgcn_s_barrier();  // all fragment reads done before the epilogue reuses the LDS
   }
   if (p.splits > 1) {  // raw fp32 slab; lane holds C[m = .. + l15][n = .. + 4g + (0..3)]
     float* slab = p.partial + (int64_t)split * p.m * p.n;
@@ -563,7 +545,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2)) void k_g
     }
     return;
   }
-  gemm_epilogue<DT, BM, BN, TM, TN>(p, acc, smem, m0, n0, wm, wn, l15, g, tid);
+  gemm_epilogue<DT, BM, BN, TM, TN, NT>(p, acc, smem, m0, n0, wm, wn, l15, g, tid);
 }
 
 // Adds the split-K slabs in split order and applies the same epilogue as gemm_epilogue (including its
@@ -659,8 +641,7 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   // and far better than 3-4 stage rings (1 block per CU).  Small grids (< 2 blocks per CU) have no
   // co-resident blocks to overlap with and keep the double buffer.
   int nbuf = nbuf_env ? nbuf_env : (blocks >= 512 ? 1 : 2);
-  if (nbuf < 1 || nbuf > 4) nbuf = 2;
-  if (nbuf > 2 && nt < nbuf) nbuf = 2;
+  if (nbuf < 1 || nbuf > 2) nbuf = 2;
   // N = 320 / 960 (every projection and conv of the 64x64-latent level): 128x160 tiles divide N
   // exactly and read the A panel 2 / 6 times instead of 5 / 15 times
   static const int t160_env = getenv("CA_GEMM_T160") ? atoi(getenv("CA_GEMM_T160")) : 1;
@@ -669,19 +650,25 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
     hipLaunchKernelGGL((k_gemm_dma<DT, 128, 160, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
     return CA_OK;
   }
+  // CA_GEMM_BIG: 0 never, 1 whenever the grid allows, unset: the wide feed-forward GEMMs only (measured
+  // +4..8% on 8192x10240x1280 and 32768x5120x640; neutral or negative on K = 320 and on the convolutions)
+  static const int big_env = getenv("CA_GEMM_BIG") ? atoi(getenv("CA_GEMM_BIG")) : -1;
+  const bool big = big_env == 1 || (big_env < 0 && MODE == 0 && p.n >= 5120 && kc >= 640);
+  if (dma && big && p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 256) * (p.n / 128) >= 512) {
+    // 256x128 tiles, 8 waves: 85 instead of 64 flop per byte moved L2 -> LDS, same 4 waves per SIMD
+    const dim3 grid(ceil_div_i(p.m, 256) * (p.n / 128));
+    hipLaunchKernelGGL((k_gemm_dma<DT, 256, 128, 4, 2, MODE, 1>), grid, dim3(512), 0, st, p);
+    return CA_OK;
+  }
   if (wide) {
     const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128));
     if (!dma) hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, st, p);
     else if (nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
-    else if (nbuf == 3) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 3>), grid, dim3(256), 0, st, p);
-    else if (nbuf == 4) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 4>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 2>), grid, dim3(256), 0, st, p);
   } else {
     const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 64));
     if (!dma) hipLaunchKernelGGL((k_gemm<DT, 128, 64, 4, 1, MODE>), grid, dim3(256), 0, st, p);
     else if (nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 1>), grid, dim3(256), 0, st, p);
-    else if (nbuf == 3) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 3>), grid, dim3(256), 0, st, p);
-    else if (nbuf == 4) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 4>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 2>), grid, dim3(256), 0, st, p);
   }
   return CA_OK;
