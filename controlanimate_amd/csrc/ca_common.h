@@ -91,7 +91,9 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return v;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp): a plain `/` expands to the ~10-instruction IEEE
+// division sequence (v_div_scale/v_div_fmas/v_div_fixup) per element, which made GroupNorm+SiLU VALU-bound.
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // erf-GELU x * Phi(x) without transcendentals: Phi(x) - 1/2 = xc * P(xc^2), xc = clamp(x, +-4.5), P a
 // degree-9 minimax-style fit (Chebyshev nodes, reweighted least squares; tools/fit_gelu.py).
 // |gelu error| <= 6e-5 for all x (the fp16 output spacing at |gelu| ~ 0.25 is 2.4e-4).  14 full-rate

@@ -69,29 +69,91 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[k][j] = ss[k][j] = 0.f;
 
-  for (int64_t r = r0 + ty; r < r1; r += TY) {
-    const int64_t row = base_row + r;
-    u32x4 raw[GN_MAX_SLOTS];
+  // two row iterations per trip: all 2 x slots loads are issued before the first use (bytes in flight)
+  // Rows are dealt to the blocks of a statistics group in TY-row pieces, round-robin: at any moment the
+  // resident blocks read ONE moving window of memory (DRAM page locality) instead of gridDim.x distant
+  // streams.  Two pieces per trip, all loads issued before the first use.
+  for (int64_t piece = chunk;; piece += 2 * (int64_t)gridDim.x) {
+    const int64_t ra = piece * TY + ty, rb = (piece + gridDim.x) * TY + ty;
+    if (piece * TY >= p.rows_per_stat) break;
+    const bool ok[2] = {ra < p.rows_per_stat, rb < p.rows_per_stat};
+    const int64_t rows2[2] = {base_row + ra, base_row + rb};
+    u32x4 raw[2][GN_MAX_SLOTS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int c8 = tx + (k << txlog);
+        if (c8 < C8 && ok[h]) {
+          const int ch = c8 << 3;
+          const int64_t rr = rows2[h];
+          raw[h][k] = ld16(ch < p.c1 ? p.x + rr * p.c1 + ch : p.x2 + rr * p.c2 + (ch - p.c1));
+        }
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        if (tx + (k << txlog) < C8 && ok[h]) {
+          float f[8];
+          unpack8<DT>(raw[h][k], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            s[k][j] += f[j];
+            ss[k][j] += f[j] * f[j];
+          }
+        }
+      }
+  }
+  const int cpg = C / p.groups;
+  if (cpg >= 8) {
+    // A 16-byte chunk (8 channels) overlaps at most two groups: reduce (first part, second part) pairs
+    // instead of 8 channels -- 4x fewer shuffles, one barrier.  Fixed order everywhere (deterministic).
+    __shared__ float part[4][GN_MAX_C / 8][4];
 #pragma unroll
     for (int k = 0; k < GN_MAX_SLOTS; ++k) {
       const int c8 = tx + (k << txlog);
-      if (c8 < C8) {
-        const int ch = c8 << 3;
-        raw[k] = ld16(ch < p.c1 ? p.x + row * p.c1 + ch : p.x2 + row * p.c2 + (ch - p.c1));
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
-      if (tx + (k << txlog) < C8) {
-        float f[8];
-        unpack8<DT>(raw[k], f);
+      if ((k << txlog) < C8) {
+        const int g0 = (c8 << 3) / cpg;
+        const int n0 = (g0 + 1) * cpg - (c8 << 3);  // channels of this chunk that belong to group g0 (>= 8: all)
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          s[k][j] += f[j];
-          ss[k][j] += f[j] * f[j];
+          if (j < n0) {
+            v[0] += s[k][j];
+            v[1] += ss[k][j];
+          } else {
+            v[2] += s[k][j];
+            v[3] += ss[k][j];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int off = TX; off < 64; off <<= 1) v[q] += __shfl_xor(v[q], off);
+        if (lane < TX && c8 < C8) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) part[wave][c8][q] = v[q];
         }
       }
     }
+    __syncthreads();
+    if (threadIdx.x < p.groups) {
+      const int g = threadIdx.x;
+      float a = 0.f, b = 0.f;
+      for (int c8 = (g * cpg) >> 3; c8 <= ((g + 1) * cpg - 1) >> 3; ++c8) {
+        const int g0 = (c8 << 3) / cpg;
+        const int q = g0 == g ? 0 : 2;
+        for (int w = 0; w < 4; ++w) {
+          a += part[w][c8][q];
+          b += part[w][c8][q + 1];
+        }
+      }
+      float* out = p.partials + (((int64_t)sg * p.nchunks + chunk) * p.groups + g) * 2;
+      out[0] = a;
+      out[1] = b;
+    }
+    return;
   }
   // deterministic reduction: row lanes of one wave by xor-shuffles (fixed tree), then the four waves
   // one after the other through LDS
@@ -130,7 +192,6 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
     }
     __syncthreads();
   }
-  const int cpg = C / p.groups;
   if (threadIdx.x < p.groups) {
     float a = 0.f, b = 0.f;
     for (int j = 0; j < cpg; ++j) {
@@ -145,46 +206,59 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
 
 template <int DT, int txlog>
 __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
-  __shared__ float sc[GN_MAX_C];
-  __shared__ float sh[GN_MAX_C];
+  __shared__ double red[8][64][2];
   __shared__ float gm[64], gr[64];
   const int C = p.c1 + p.c2, C8 = C >> 3;
   constexpr int TX = 1 << txlog, TY = 256 >> txlog;
   const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> txlog;
   const int chunk = blockIdx.x, sg = blockIdx.y;
   const int cpg = C / p.groups;
-  if (threadIdx.x < p.groups) {
-    double a = 0.0, b = 0.0;
-    const float* part = p.partials + ((int64_t)sg * p.nchunks * p.groups + threadIdx.x) * 2;
-    for (int k = 0; k < p.nchunks; ++k) {
-      a += (double)part[(int64_t)k * p.groups * 2];
-      b += (double)part[(int64_t)k * p.groups * 2 + 1];
+  {
+    // partial sums of this statistics group: 256 threads = (slot, group), each slot adds every S-th chunk
+    // in fp64, then the slots are added in order (deterministic; 2 dependent loads instead of nchunks)
+    const int S = p.groups <= 32 ? 8 : 4;
+    const int g = threadIdx.x % (256 / S), slot = threadIdx.x / (256 / S);
+    if (g < p.groups) {
+      double a = 0.0, b = 0.0;
+      const float* part = p.partials + ((int64_t)sg * p.nchunks * p.groups + g) * 2;
+      for (int k = slot; k < p.nchunks; k += S) {
+        const float2 v = *reinterpret_cast<const float2*>(part + (int64_t)k * p.groups * 2);
+        a += (double)v.x;
+        b += (double)v.y;
+      }
+      red[slot][g][0] = a;
+      red[slot][g][1] = b;
     }
-    const double cnt = (double)p.rows_per_stat * (double)cpg;
-    const double mean = a / cnt;
-    double var = b / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    gm[threadIdx.x] = (float)mean;
-    gr[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
+    __syncthreads();
+    if (threadIdx.x < p.groups) {
+      double a = 0.0, b = 0.0;
+      for (int q = 0; q < S; ++q) {
+        a += red[q][threadIdx.x][0];
+        b += red[q][threadIdx.x][1];
+      }
+      const double cnt = (double)p.rows_per_stat * (double)cpg;
+      const double mean = a / cnt;
+      double var = b / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      gm[threadIdx.x] = (float)mean;
+      gr[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int gi = c / cpg;
-    const float scale = gr[gi] * p.gamma[c];
-    sc[c] = scale;
-    sh[c] = p.beta[c] - gm[gi] * scale;
-  }
-  __syncthreads();
   // this thread's channels are the same for every row: keep their scale/shift in registers
   float rs[GN_MAX_SLOTS][8], rh[GN_MAX_SLOTS][8];
 #pragma unroll
   for (int k = 0; k < GN_MAX_SLOTS; ++k) {
     const int c8 = tx + (k << txlog);
     if (c8 < C8) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + (c8 << 3)), g1 = *reinterpret_cast<const f32x4*>(p.gamma + (c8 << 3) + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + (c8 << 3)), b1 = *reinterpret_cast<const f32x4*>(p.beta + (c8 << 3) + 4);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        rs[k][j] = sc[(c8 << 3) + j];
-        rh[k][j] = sh[(c8 << 3) + j];
+        const int gi = ((c8 << 3) + j) / cpg;
+        const float scale = gr[gi] * (j < 4 ? g0[j & 3] : g1[j & 3]);
+        rs[k][j] = scale;
+        rh[k][j] = (j < 4 ? b0[j & 3] : b1[j & 3]) - gm[gi] * scale;
       }
     }
   }
@@ -192,31 +266,39 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
   int64_t r1 = r0 + p.rows_per_chunk;
   if (r1 > p.rows_per_stat) r1 = p.rows_per_stat;
   const int64_t base_row = (int64_t)sg * p.rows_per_stat;
-  for (int64_t r = r0 + ty; r < r1; r += TY) {
-    const int64_t row = base_row + r;
-    u32x4 raw[GN_MAX_SLOTS];
+  for (int64_t piece = chunk;; piece += 2 * (int64_t)gridDim.x) {  // same round-robin dealing as the statistics pass
+    const int64_t ra = piece * TY + ty, rb = (piece + gridDim.x) * TY + ty;
+    if (piece * TY >= p.rows_per_stat) break;
+    const bool ok[2] = {ra < p.rows_per_stat, rb < p.rows_per_stat};
+    const int64_t rows2[2] = {base_row + ra, base_row + rb};
+    u32x4 raw[2][GN_MAX_SLOTS];
 #pragma unroll
-    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
-      const int c8 = tx + (k << txlog);
-      if (c8 < C8) {
-        const int ch = c8 << 3;
-        raw[k] = ld16(ch < p.c1 ? p.x + row * p.c1 + ch : p.x2 + row * p.c2 + (ch - p.c1));
-      }
-    }
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
-      const int c8 = tx + (k << txlog);
-      if (c8 < C8) {
-        float f[8];
-        unpack8<DT>(raw[k], f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = f[j] * rs[k][j] + rh[k][j];
-          f[j] = p.act == CA_ACT_SILU ? silu_f(v) : v;
+      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int c8 = tx + (k << txlog);
+        if (c8 < C8 && ok[h]) {
+          const int ch = c8 << 3;
+          const int64_t rr = rows2[h];
+          raw[h][k] = ld16(ch < p.c1 ? p.x + rr * p.c1 + ch : p.x2 + rr * p.c2 + (ch - p.c1));
         }
-        st16(p.y + row * C + (c8 << 3), pack8<DT>(f));
       }
-    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int c8 = tx + (k << txlog);
+        if (c8 < C8 && ok[h]) {
+          float f[8];
+          unpack8<DT>(raw[h][k], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v = f[j] * rs[k][j] + rh[k][j];
+            f[j] = p.act == CA_ACT_SILU ? silu_f(v) : v;
+          }
+          st16(p.y + rows2[h] * C + (c8 << 3), pack8<DT>(f));
+        }
+      }
   }
 }
 
@@ -427,7 +509,7 @@ extern "C" int ca_groupnorm_apply(const ca_groupnorm_args* a, void* stream) {
   int rc = gn_fill(a, p, "ca_groupnorm_apply");
   if (rc) return rc;
   CA_REQUIRE(a->y && a->gamma && a->beta, "ca_groupnorm_apply: null operand");
-  const int achunks = gn_chunks_rows(p.rows_per_stat, 64);
+  const int achunks = gn_chunks_rows(p.rows_per_stat, p.rows_per_stat >= 2048 ? 128 : 64);
   p.rows_per_chunk = (p.rows_per_stat + achunks - 1) / achunks;
   dim3 grid(achunks, a->images / a->frames_per_stat);
   if (a->dtype == CA_BF16) launch_gn<CA_BF16>(true, p, grid, (hipStream_t)stream);
