@@ -26,6 +26,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 EXTRA = {"ca_attention.hip": ["-fno-honor-nans"]}  # see vmax3 in ca_common.h
 
 
+def _extra_env_flags() -> list:
+    """CA_HIPCC_FLAGS="-DX=1 ..." appends flags (timing experiments, e.g. the CA_GEMM_ABLATE switches)."""
+    return os.environ.get("CA_HIPCC_FLAGS", "").split()
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.sep not in cand or os.path.exists(cand)):
@@ -50,7 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *EXTRA.get(s, []), *_extra_env_flags(), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

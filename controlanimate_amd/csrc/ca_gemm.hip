@@ -51,6 +51,9 @@ struct GemmKParams {
 };
 
 constexpr int BK = 64;
+#ifndef CA_GEMM_ABLATE
+#define CA_GEMM_ABLATE 0  // timing experiments only: 1 = no MFMA / fragment reads (DMA + barriers only), 2 = no DMA after tile 0
+#endif
 
 // Tile order inside an XCD's contiguous id range: groups of GROUP_M row-tiles are swept column by
 // column, so the ~128 blocks resident on an XCD share 8 A panels and ~16 W panels in its 4 MB L2.
@@ -376,16 +379,25 @@ constexpr unsigned DMA_OOB = 0xFFFFFFF0u;  // beyond any descriptor size we acce
 //           `s_waitcnt vmcnt(per-tile DMA count)` (tile t landed, tile t+1 may still be in flight),
 //           then a raw s_barrier: DMA transfers stay in flight across barriers
 //           (cdna_hip_programming.md "Pipelining across barriers").  All LDS is one array.
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (NBUF == 1 ? (BN > 128 ? 3 : 4) : 2) * 4 / (WAVES_M * WAVES_N))
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF, int KT = 64>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (NBUF * KT == 64 ? (BN > 128 ? 3 : 4) : 2) * 4 / (WAVES_M * WAVES_N))
 void k_gemm_dma(GemmKParams p) {
+  // KT = K elements per LDS stage: 64 (one 128-byte row per tile row) or 32 with NBUF = 2 -- the same 32 KB
+  // as one 64-wide stage, so 4 blocks still share a CU, but each block also prefetches its own next stage
+  static_assert(KT == 64 || KT == 32, "k tile");
+  constexpr int CPR = KT / 8;        // 16-byte chunks per LDS row
+  constexpr int RPI = 64 / CPR;      // tile rows one wave-wide DMA instruction covers
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;  // 4 waves (128-row tiles) or 8 waves (256x128 tiles)
   constexpr int TM = BM / WAVES_M / 16;
   constexpr int TN = BN / WAVES_N / 16;
-  constexpr int AG = BM / 8 / NW;  // 8-row groups staged per wave (A)
-  constexpr int BG = BN / 8 / NW;  // (W)
+  constexpr int AG = BM / RPI / NW;  // DMA instructions per wave per stage (A)
+  constexpr int BG = BN / RPI / NW;  // (W)
   // the LDS-staged epilogue needs BM x (BN + 8) elements: more than ONE 128x128x64 stage
-  constexpr int SMEM_ELEMS = NBUF * (BM + BN) * BK > BM * (BN + 8) ? NBUF * (BM + BN) * BK : BM * (BN + 8);
+  constexpr int SMEM_ELEMS = NBUF * (BM + BN) * KT > BM * (BN + 8) ? NBUF * (BM + BN) * KT : BM * (BN + 8);
+  // XOR swizzle of the chunk index: conflict-free ds_read_b128 for the hardware's 16-lane groups
+  // (128-byte rows: (row>>1)&7; 64-byte rows: the map [0,3,2,1][(row>>2)&3] = (-(row>>2))&3)
+  auto swz = [](int row) { return KT == 64 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3); };
+  auto lds_at = [&](int row, int chunk) { return row * KT + ((chunk ^ swz(row)) << 3); };
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_ELEMS];
 
   const int tid = threadIdx.x;
@@ -410,8 +422,9 @@ void k_gemm_dma(GemmKParams p) {
   const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, p.a2 ? p.a2_bytes : p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
-  const int r8 = lane >> 3, cp = lane & 7;  // row inside an 8-row group, LDS chunk position
+  const int r8 = lane / CPR, cp = lane % CPR;  // row inside a DMA row group, LDS chunk position
   const int kc = p.c1 + p.c2;
+  const int kct = kc / KT;  // K tiles per tap (the DMA path requires kc % 64 == 0)
   const unsigned wld = (unsigned)(p.taps * kc);
 
   // per staged row: swizzled source chunk, and either a byte offset (dense / weights) or pixel coords (conv)
@@ -420,8 +433,8 @@ void k_gemm_dma(GemmKParams p) {
   bool a_ok[AG];
 #pragma unroll
   for (int i = 0; i < AG; ++i) {
-    const int row = (wid * AG + i) * 8 + r8;
-    a_chunk[i] = cp ^ ((row >> 1) & 7);
+    const int row = (wid * AG + i) * RPI + r8;
+    a_chunk[i] = cp ^ swz(row);
     const int m = m0 + row;
     a_ok[i] = m < p.m;
     const int mm = a_ok[i] ? m : p.m - 1;
@@ -442,26 +455,26 @@ void k_gemm_dma(GemmKParams p) {
   unsigned b_off[BG];
 #pragma unroll
   for (int j = 0; j < BG; ++j) {
-    const int row = (wid * BG + j) * 8 + r8;
-    b_chunk[j] = cp ^ ((row >> 1) & 7);
+    const int row = (wid * BG + j) * RPI + r8;
+    b_chunk[j] = cp ^ swz(row);
     int n = n0 + row;
     if (n >= p.n) n = p.n - 1;  // clamped rows feed accumulators that are never stored
     b_off[j] = (unsigned)n * wld * 2u;
   }
 
   auto stage = [&](int t, int buf) {
-    u16* sa = smem + buf * (BM + BN) * BK;
-    u16* sb = sa + BM * BK;
-    const int tap = (p.taps == 1) ? 0 : t / p.kc_tiles;
-    const int cc = t - tap * p.kc_tiles;
-    const int c0 = cc * BK;            // first channel of this K tile (tile-uniform)
+    u16* sa = smem + buf * (BM + BN) * KT;
+    u16* sb = sa + BM * KT;
+    const int tap = (p.taps == 1) ? 0 : t / kct;
+    const int cc = t - tap * kct;
+    const int c0 = cc * KT;            // first channel of this K tile (tile-uniform)
     const bool src2 = c0 >= p.c1;      // c1 % 64 == 0 => a tile never straddles the two sources
     const int cs = src2 ? p.c2 : p.c1;
     const int cbase = src2 ? c0 - p.c1 : c0;
 #pragma unroll
     for (int j = 0; j < BG; ++j) {
       const unsigned off = b_off[j] + (unsigned)(tap * kc + c0 + b_chunk[j] * 8) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(sb + (wid * BG + j) * 8 * BK), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(sb + (wid * BG + j) * RPI * KT), 16, off, 0, 0, 0);
     }
     if (MODE == 1) {
       const int kh = tap / 3, kw = tap - kh * 3;
@@ -472,7 +485,7 @@ void k_gemm_dma(GemmKParams p) {
         const bool ok = a_ok[i] && hi >= 0 && wi >= 0 && hi < (p.hin << p.ups) && wi < (p.win << p.ups);
         const int pix = (a_img[i] * p.hin + (hi >> p.ups)) * p.win + (wi >> p.ups);
         const unsigned off = ok ? ((unsigned)pix * (unsigned)cs + (unsigned)(cbase + a_chunk[i] * 8)) * 2u : DMA_OOB;
-        void* dst = sa + (wid * AG + i) * 8 * BK;
+        void* dst = sa + (wid * AG + i) * RPI * KT;
         if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
       }
@@ -480,7 +493,7 @@ void k_gemm_dma(GemmKParams p) {
 #pragma unroll
       for (int i = 0; i < AG; ++i) {
         const unsigned off = (src2 ? a_off2[i] : a_off1[i]) + (unsigned)(cbase + a_chunk[i] * 8) * 2u;
-        void* dst = sa + (wid * AG + i) * 8 * BK;
+        void* dst = sa + (wid * AG + i) * RPI * KT;
         if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
       }
@@ -493,19 +506,20 @@ void k_gemm_dma(GemmKParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nt_all = p.taps * p.kc_tiles;
+  const int nt_all = p.taps * kct;
   const int t_first = p.splits > 1 ? (int)((int64_t)nt_all * split / p.splits) : 0;
   const int nt = (p.splits > 1 ? (int)((int64_t)nt_all * (split + 1) / p.splits) : nt_all) - t_first;
   auto compute = [&](int buf) {
-    const u16* sa = smem + buf * (BM + BN) * BK;
-    const u16* sb = sa + BM * BK;
+    const u16* sa = smem + buf * (BM + BN) * KT;
+    const u16* sb = sa + BM * KT;
+    if (CA_GEMM_ABLATE == 1) return;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < KT / 32; ++s) {
       u32x4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = ld16(sa + lds_off(wm * TM * 16 + i * 16 + l15, s * 4 + g));
+      for (int i = 0; i < TM; ++i) fa[i] = ld16(sa + lds_at(wm * TM * 16 + i * 16 + l15, s * 4 + g));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = ld16(sb + lds_off(wn * TN * 16 + j * 16 + l15, s * 4 + g));
+      for (int j = 0; j < TN; ++j) fb[j] = ld16(sb + lds_at(wn * TN * 16 + j * 16 + l15, s * 4 + g));
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -516,7 +530,7 @@ void k_gemm_dma(GemmKParams p) {
     // single LDS buffer (32 KB for 128x128): two barriers per tile, but 3 blocks per CU -- the
     // other resident blocks' MFMA phases cover this block's transfer latency
     for (int t = 0; t < nt; ++t) {
-      stage(t_first + t, 0);
+      if (CA_GEMM_ABLATE != 2 || t == 0) stage(t_first + t, 0);
       __syncthreads();
       compute(0);
       __syncthreads();
@@ -658,6 +672,12 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
     // 256x128 tiles, 8 waves: 85 instead of 64 flop per byte moved L2 -> LDS, same 4 waves per SIMD
     const dim3 grid(ceil_div_i(p.m, 256) * (p.n / 128));
     hipLaunchKernelGGL((k_gemm_dma<DT, 256, 128, 4, 2, MODE, 1>), grid, dim3(512), 0, st, p);
+    return CA_OK;
+  }
+  static const int kt_env = getenv("CA_GEMM_KT") ? atoi(getenv("CA_GEMM_KT")) : 64;
+  if (wide && dma && kt_env == 32) {
+    const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128));
+    hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 2, 32>), grid, dim3(256), 0, st, p);
     return CA_OK;
   }
   if (wide) {
