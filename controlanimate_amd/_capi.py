@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcontrolanimate_hip.so")
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CAHipUnavailable(RuntimeError):
@@ -81,7 +81,7 @@ class AttnArgs(C.Structure):
         ("batches", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("nq", C.c_int32), ("nk", C.c_int32),
         ("scale", C.c_float), ("out_scale", C.c_float),
-        ("accumulate", C.c_int32), ("dtype", C.c_int32),
+        ("accumulate", C.c_int32), ("dtype", C.c_int32), ("causal", C.c_int32),
     ]
 
 

@@ -39,6 +39,7 @@ struct AttnKParams {
   float out_scale;
   int accumulate;
   int sum_row;  // 1: V^T row `head_dim` is all ones, so the PV MFMA also produces the softmax row sums
+  int causal;   // 1: key j is visible to query i only if j <= i (CLIP text encoder); generic kernel only
 };
 
 template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool PF>
@@ -226,12 +227,15 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     bool grow = false;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      if (TAIL) {
+      if (TAIL) {  // (also every tile of a causal launch)
+        const int qlim = p.causal ? q0 + t * 16 + l15 : 0x7fffffff;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (kv0 + kt * 16 + g * 4 + r >= p.nk) sacc[t][kt][r] = -INFINITY;
+          for (int r = 0; r < 4; ++r) {
+            const int key = kv0 + kt * 16 + g * 4 + r;
+            if (key >= p.nk || key > qlim) sacc[t][kt][r] = -INFINITY;
+          }
       }
       float m = vmax3(sacc[t][0][0], sacc[t][0][1], sacc[t][0][2]);
       m = vmax2(m, sacc[t][0][3]);
@@ -301,7 +305,11 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   {
     const int nfull = p.nk / KB;
     int iter = 0;
-    for (; iter < nfull; ++iter) tile_body(iter * KB, iter, BoolC<false>{});
+    if (p.causal) {
+      for (; iter < nfull; ++iter) tile_body(iter * KB, iter, BoolC<true>{});
+    } else {
+      for (; iter < nfull; ++iter) tile_body(iter * KB, iter, BoolC<false>{});
+    }
     if (nfull * KB < p.nk) tile_body(nfull * KB, iter, BoolC<true>{});
   }
 
@@ -613,10 +621,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
 template <int DT, int DK32, int DV16>
 void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
   AttnKParams p = p0;
-  if (p.nq <= 16 && p.nk <= 32) {
+  if (p.nq <= 16 && p.nk <= 32 && !p.causal) {
     p.qblocks = 1;
     hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 1, 1, 32, false>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
-  } else if (p.nq <= 32 && p.nk <= 32) {
+  } else if (p.nq <= 32 && p.nk <= 32 && !p.causal) {
     p.qblocks = 1;
     hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 1, 32, false>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
   } else {
@@ -625,7 +633,7 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
     p.qblocks = ceil_div_i(p.nq, 128);
     const dim3 grid((unsigned)(p.qblocks * p.batches * p.heads));
     static const int dma_env = getenv("CA_ATTN_DMA") ? atoi(getenv("CA_ATTN_DMA")) : 1;
-    if (DK32 <= 2 && dma_env && p.nk >= 256 && p.k_row % 8 == 0 &&
+    if (DK32 <= 2 && dma_env && !p.causal && p.nk >= 256 && p.k_row % 8 == 0 &&
         ((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2 < (int64_t)0xFFFFFF00ll) {
       // the ones column needs a free, 16-byte aligned pad chunk inside the last 16-wide dv tile
       static const int sr_env = getenv("CA_ATTN_SR") ? atoi(getenv("CA_ATTN_SR")) : 1;
@@ -696,6 +704,8 @@ extern "C" int ca_attention(const ca_attn_args* a, void* stream) {
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.out_scale = a->out_scale;
   p.accumulate = a->accumulate;
+  p.causal = a->causal ? 1 : 0;
+  CA_REQUIRE(!a->causal || a->nq == a->nk, "ca_attention: causal needs nq == nk");
   {
     const int d = a->head_dim;
     const int dvp = d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : d <= 80 ? 80 : d <= 128 ? 128 : 160;

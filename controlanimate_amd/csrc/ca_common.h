@@ -115,6 +115,14 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return fmaf(x, xc * p, 0.5f * x);
 }
 
+// epilogue activation selected at run time (wave-uniform)
+__device__ __forceinline__ float act_f(float x, int act) {
+  if (act == CA_ACT_SILU) return silu_f(x);
+  if (act == CA_ACT_QUICK_GELU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+  if (act == CA_ACT_GELU) return gelu_erf_f(x);
+  return x;
+}
+
 // Three-/two-input max.  Written with fmaxf so the compiler sees the data dependence on MFMA results
 // (its hazard recogniser does not look inside inline asm: a hand-written v_max3_f32 read the
 // accumulators too early).  Files whose max chains consume MFMA output are compiled with

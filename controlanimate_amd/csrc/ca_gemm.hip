@@ -110,9 +110,9 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmKParams& p, f32x4
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] *= p.post;
-      if (p.act == CA_ACT_SILU) {
+      if (p.act != CA_ACT_NONE) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], p.act);
       }
       if (p.geglu) {
         float o0 = v[0] * gelu_erf_f(v[1]);
@@ -202,9 +202,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= p.post;
-    if (p.act == CA_ACT_SILU) {
+    if (p.act != CA_ACT_NONE) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = silu_f(v[k]);
+      for (int k = 0; k < 8; ++k) v[k] = act_f(v[k], p.act);
     }
     if (p.geglu) {
       float o[4];
@@ -603,9 +603,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmKParams p) {
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) v[k] *= p.post;
-  if (p.act == CA_ACT_SILU) {
+  if (p.act != CA_ACT_NONE) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = silu_f(v[k]);
+    for (int k = 0; k < 8; ++k) v[k] = act_f(v[k], p.act);
   }
   const int64_t off = m * p.ldc + n;
   if (p.out_f32) {

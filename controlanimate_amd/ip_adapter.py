@@ -10,8 +10,8 @@ Follows the reference's modules/ip_adapter.py:
                                   (x3), mid
   set_scale (:200-203), ImageProjModel (:30-47), get_image_embeds(_4controlanimate) (:187-222)
 The CLIP vision encoder that produces `clip_image_embeds` [n,1024] runs once per window, not per
-step, and is out of scope: pass an `image_encoder` callable (PIL -> [1,1024]) or
-the embeds themselves.
+step: pass `image_encoder=` a controlanimate_amd.clip.CLIPVisionModelWithProjection (HIP; the images go
+through clip_preprocess first), any callable (PIL -> [1,1024]), or the embeds themselves.
 """
 from __future__ import annotations
 
@@ -145,8 +145,13 @@ class IPAdapter:
     def get_image_embeds(self, pil_image=None, clip_image_embeds=None):
         if pil_image is not None:
             if self.image_encoder is None:
-                raise RuntimeError("no image_encoder attached: pass clip_image_embeds (CLIP vision is out of scope)")
-            clip_image_embeds = self.image_encoder(pil_image)
+                raise RuntimeError("no image_encoder attached: pass clip_image_embeds or an image_encoder")
+            if hasattr(self.image_encoder, "vision_model"):  # HIP CLIPVisionModelWithProjection (reference :190-193)
+                from .clip import clip_preprocess
+                px = clip_preprocess(pil_image, self.image_encoder.config.image_size)
+                clip_image_embeds = self.image_encoder(px.to(self.device)).image_embeds.float()
+            else:
+                clip_image_embeds = self.image_encoder(pil_image)
         clip_image_embeds = clip_image_embeds.to(self.device)
         tokens = self.image_proj_model(clip_image_embeds)
         uncond = self.image_proj_model(torch.zeros_like(clip_image_embeds))

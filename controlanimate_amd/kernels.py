@@ -15,6 +15,7 @@ from ._capi import (AttnArgs, ConvArgs, GemmArgs, GroupNormArgs, LayerNormArgs, 
                     CA_ACT_SILU, CA_BF16, CA_F16, check, lib)
 
 ACT_NONE, ACT_SILU = CA_ACT_NONE, CA_ACT_SILU
+ACT_QUICK_GELU, ACT_GELU = 2, 3  # CA_ACT_QUICK_GELU / CA_ACT_GELU (CLIP MLPs)
 
 
 def dt_code(dtype: torch.dtype) -> int:
@@ -159,7 +160,7 @@ def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, pos:
 def attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, *, q_off: int, k_off: int,
                   v_off: int, o_off: int, q_strides, o_strides, k_strides, inner_count: int, kv_inner_count: int,
                   kv_div: int, batches: int, heads: int, head_dim: int, nq: int, nk: int, scale: float,
-                  out_scale: float = 1.0, accumulate: bool = False, kv_mod: int = 0) -> None:
+                  out_scale: float = 1.0, accumulate: bool = False, kv_mod: int = 0, causal: bool = False) -> None:
     """Direct mapping of ca_attention. *_off are element offsets into the given storage tensors;
     *_strides = (outer, inner, row) in elements."""
     _req_cuda(q, k, v, o)
@@ -171,11 +172,11 @@ def attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Te
                     k_outer=k_strides[0], k_inner=k_strides[1], k_row=k_strides[2],
                     inner_count=inner_count, kv_inner_count=kv_inner_count, kv_div=kv_div,
                     kv_mod=kv_mod if kv_mod > 0 else batches, batches=batches, heads=heads, head_dim=head_dim, nq=nq, nk=nk, scale=scale, out_scale=out_scale,
-                    accumulate=int(accumulate), dtype=dt_code(q.dtype))
+                    accumulate=int(accumulate), dtype=dt_code(q.dtype), causal=int(causal))
     check(lib().ca_attention(C.byref(args), _stream()), "ca_attention")
 
 
-def attention_spatial(qkv: torch.Tensor, images: int, tokens: int, heads: int) -> torch.Tensor:
+def attention_spatial(qkv: torch.Tensor, images: int, tokens: int, heads: int, causal: bool = False) -> torch.Tensor:
     """Self-attention per image. qkv: [images*tokens, 3C] (q | k | v); returns [images*tokens, C]."""
     c = qkv.shape[1] // 3
     d = c // heads
@@ -184,7 +185,7 @@ def attention_spatial(qkv: torch.Tensor, images: int, tokens: int, heads: int) -
     attention_raw(qkv, qkv, qkv, o, q_off=0, k_off=c, v_off=2 * c, o_off=0,
                   q_strides=(tokens * ld, 0, ld), o_strides=(tokens * c, 0, c), k_strides=(tokens * ld, 0, ld),
                   inner_count=1, kv_inner_count=1, kv_div=1, batches=images, heads=heads, head_dim=d,
-                  nq=tokens, nk=tokens, scale=d ** -0.5)
+                  nq=tokens, nk=tokens, scale=d ** -0.5, causal=causal)
     return o
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 2
+#define CA_ABI_VERSION 3
 
 /* element types */
 #define CA_BF16 0
@@ -41,6 +41,8 @@ extern "C" {
 /* epilogue activations */
 #define CA_ACT_NONE 0
 #define CA_ACT_SILU 1
+#define CA_ACT_QUICK_GELU 2 /* x * sigmoid(1.702 x): CLIP ViT-L text/vision MLPs */
+#define CA_ACT_GELU 3       /* erf GELU: CLIP ViT-H vision MLP (IP-Adapter image encoder) */
 
 int ca_abi_version(void);
 const char* ca_last_error(void);
@@ -229,6 +231,9 @@ typedef struct ca_attn_args {
   float out_scale;      /* multiplies the attention output */
   int32_t accumulate;   /* 1: O += out_scale * attn */
   int32_t dtype;
+  int32_t causal;       /* 1: key j visible to query i only if j <= i (nq == nk).  CLIP text encoder
+                           (transformers CLIPTextModel's causal mask; called through Compel at
+                           modules/controlanimate_pipeline.py:133-135) */
 } ca_attn_args;
 int ca_attention(const ca_attn_args* args, void* stream);
 

@@ -312,6 +312,35 @@ def test_attention_spatial(images, tokens, heads, d, dtype):
     close(out, ref, dtype, f"attn_spatial({images},{tokens},{heads},{d})", rel=8e-3 if dtype == torch.bfloat16 else 3e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("images,tokens,heads,d", [(2, 77, 12, 64), (1, 16, 4, 16), (2, 130, 2, 80)])
+def test_attention_causal(images, tokens, heads, d, dtype):
+    """CLIP text encoder: key j is visible to query i only if j <= i."""
+    k = _k()
+    c = heads * d
+    qkv = rnd(images * tokens, 3 * c, dtype=dtype, seed=43)
+    q, kk, v = [t.float().reshape(images, tokens, heads, d).transpose(1, 2) for t in qkv.split(c, dim=1)]
+    ref = F.scaled_dot_product_attention(q, kk, v, is_causal=True).transpose(1, 2).reshape(images * tokens, c)
+    out = k.attention_spatial(qkv.to(DEV), images, tokens, heads, causal=True)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, f"attn_causal({images},{tokens},{heads},{d})", rel=8e-3 if dtype == torch.bfloat16 else 3e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [2, 3])
+def test_gemm_clip_activations(act, dtype):
+    """CA_ACT_QUICK_GELU (x * sigmoid(1.702 x)) and CA_ACT_GELU (erf) epilogues."""
+    k = _k()
+    a = rnd(154, 768, dtype=dtype, seed=51)
+    w = rnd(3072, 768, dtype=dtype, scale=768 ** -0.5, seed=52)
+    b = rnd(3072, dtype=torch.float32, seed=53)
+    y = a.float() @ w.float().t() + b
+    ref = y * torch.sigmoid(1.702 * y) if act == 2 else F.gelu(y)
+    out = k.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), act=act)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, f"gemm act {act}")
+
+
 def test_attention_online_softmax_rescale():
     """A spiked key in a LATER kv block forces the running-max rescale branch."""
     k = _k()
