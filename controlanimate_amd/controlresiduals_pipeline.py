@@ -10,8 +10,9 @@ Same call surface as the reference's modules/controlresiduals_pipeline.py:
     attributes .controlnet (.nets, .half(), .dtype), .controlnets, .cond_scale, .controlnet_names.
 
 The returned residuals are [b,C,f,h,w] VIEWS of channels-last storage, which the UNet consumes
-without a copy (unet.py `_to_nhwc`).  Annotators (canny / openpose / ... detectors,
-reference :97-150) are third-party pre-processing outside the loop and are NOT rebuilt: pass
+without a copy (unet.py `_to_nhwc`).  Annotators (reference :97-150): canny is built in
+(controlanimate_amd/annotators.py, a numpy restatement of cv2.Canny(img, 100, 200)); the learned detectors
+(openpose / hed / lineart / mlsd / depth) are third-party models outside the loop and are NOT rebuilt: pass
 already-annotated control images, or plug callables in through `annotators`.
 """
 from __future__ import annotations
@@ -56,7 +57,9 @@ class MultiControlNetResidualsPipeline:
         self.cond_scale = list(cond_scale)
         self.use_lcm = use_lcm
         self.ip_adapter = None
-        self.annotators = dict(annotators or {})
+        from .annotators import canny
+        self.canny_processor = canny
+        self.annotators = {"canny": canny, **dict(annotators or {})}
         self.prep_images: Optional[List[torch.Tensor]] = None
         self.device = torch.device(device)
 
