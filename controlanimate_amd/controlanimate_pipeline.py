@@ -8,13 +8,16 @@ and the config keys it reads (inference_config_path / motion_module / use_lcm / 
 cond_scale / scheduler / use_ipadapter / seed / width / height / steps / strength / guidance_scale /
 frame_count / overlaps / epoch / guess_mode / ipa_scale / use_img2img ...).
 
-What is NOT rebuilt here (SURVEY 8f "next"; host-side, once per run or per window): Hugging Face
-checkpoint download/loading, the CLIP tokenizer/text encoder + Compel prompt weighting, the VAE,
-DreamBooth/LoRA conversion, textual inversion.  They are injected instead:
-    components = dict(unet=UNet3DConditionModel, controlnets=[ControlNetModel...], vae=None|obj,
-                      encode_prompt=callable(str)->Tensor[1,77,768], ip_adapter_ckpt=None|dict,
-                      image_encoder=None|callable)
-so a maintainer wires the reference's own loaders to these objects.
+Models are injected (there is no network for Hugging Face downloads):
+    components = dict(unet=UNet3DConditionModel, controlnets=[ControlNetModel...],
+                      vae=None | controlanimate_amd.vae.AutoencoderKL | any diffusers-style VAE,
+                      text_encoder=None | controlanimate_amd.clip.CLIPTextModel, tokenizer=None | CLIPTokenizer,
+                      encode_prompt=None | callable(str)->Tensor[1,77,768]   (e.g. the reference's Compel object),
+                      ip_adapter_ckpt=None|dict, image_encoder=None | clip.CLIPVisionModelWithProjection | callable)
+With text_encoder + tokenizer and no encode_prompt the prompt is encoded unweighted (what Compel returns
+for a prompt without weighting syntax; Compel itself, :133-135, is third-party host code and not rebuilt).
+Checkpoint conversion / LoRA fusing: controlanimate_amd.weight_ingest.  With a VAE attached `animate`
+returns PIL frames like the reference (:166, modules/utils.py:74-85); without one it returns the latents.
 """
 from __future__ import annotations
 
@@ -47,9 +50,11 @@ class ControlAnimatePipeline:
             device=self.device, annotators=components.get("annotators")) if nets else None
         noise_kwargs = dict(components.get("noise_scheduler_kwargs") or NOISE_SCHEDULER_KWARGS)
         scheduler = None if self.use_lcm else get_scheduler(_get(config, "scheduler", "DDIMScheduler"), **noise_kwargs)
-        self.pipeline = ControlAnimationPipeline(vae=components.get("vae"), text_encoder=None, tokenizer=None, unet=unet,
-                                                 scheduler=scheduler).to(self.device)
+        self.pipeline = ControlAnimationPipeline(vae=components.get("vae"), text_encoder=components.get("text_encoder"),
+                                                 tokenizer=components.get("tokenizer"), unet=unet, scheduler=scheduler).to(self.device)
         self.encode_prompt: Optional[Callable] = components.get("encode_prompt")
+        if self.encode_prompt is None and self.pipeline.text_encoder is not None and self.pipeline.tokenizer is not None:
+            self.encode_prompt = self._encode_plain
         self.use_ipadapter = bool(_get(config, "use_ipadapter", 0))
         if self.use_ipadapter:
             ip = IPAdapter(self.pipeline, components.get("image_encoder"), components.get("ip_adapter_ckpt"), self.device, num_tokens=4)
@@ -64,6 +69,12 @@ class ControlAnimatePipeline:
         self.prompt = _get(config, "prompt", "")
         self.n_prompt = _get(config, "n_prompt", "")
         self._embeds = components.get("prompt_embeds"), components.get("negative_prompt_embeds")
+
+    def _encode_plain(self, prompt: str) -> torch.Tensor:
+        tok = self.pipeline.tokenizer
+        ids = tok(prompt, padding="max_length", max_length=getattr(tok, "model_max_length", 77), truncation=True,
+                  return_tensors="pt").input_ids
+        return self.pipeline.text_encoder(ids.to(self.device))[0]
 
     def _prompt_embeds(self):
         if self._embeds[0] is not None:
@@ -89,4 +100,18 @@ class ControlAnimatePipeline:
             save_outputs=bool(_get(config, "save_frames", 0)), last_output_frames=last_output_frames, use_lcm=self.use_lcm,
             guess_mode=bool(_get(config, "guess_mode", 0)), ipa_scale=float(_get(config, "ipa_scale", 0.4)),
             use_img2img=bool(_get(config, "use_img2img", False)), **extra)
-        return out.videos
+        videos = out.videos
+        if self.pipeline.vae is None or extra.get("output_type") == "latent":
+            return videos
+        return frames_to_pil(videos)
+
+
+def frames_to_pil(videos) -> List:
+    """modules/utils.py:74-85 get_frames_pil_images: [b,c,t,h,w] in [0,1] -> list of (t b) PIL images
+    (`(x * 255).astype(uint8)`: truncation, as the reference)."""
+    import numpy as np
+    from PIL import Image
+    v = torch.as_tensor(videos).float().cpu()
+    frames = v.permute(2, 0, 3, 4, 1).reshape(-1, v.shape[3], v.shape[4], v.shape[1])
+    return [Image.fromarray((x * 255).numpy().astype(np.uint8).squeeze(-1) if x.shape[-1] == 1 else (x * 255).numpy().astype(np.uint8))
+            for x in frames]
