@@ -348,7 +348,7 @@ def main():
         timer.enabled = False
         graph_state["graph"] = gr
     vae_ms = None
-    if not args.no_vae and rank == 0:
+    if not args.no_vae and world == 1:  # single-GPU runs only: the other ranks of a scaling run must not wait for it
         vae_ms = time_vae(args, device, dtype)
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)

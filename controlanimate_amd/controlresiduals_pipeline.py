@@ -65,6 +65,8 @@ class MultiControlNetResidualsPipeline:
 
     # ------------------------------------------------------------------------------------------
     def prepare_controlnet_input_image(self, controlnet_model: str, image):
+        if isinstance(image, torch.Tensor):
+            return image  # tensors are control images that are already annotated / preprocessed
         for key, fn in self.annotators.items():
             if key in controlnet_model:
                 return fn(image)

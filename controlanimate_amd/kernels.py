@@ -98,7 +98,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
     y = torch.empty((images, hout, wout, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     ld_res = 0
     if residual is not None:
-        assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == images * hout * wout * cout
+        assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == images * hout * wout * cout, \
+            f"residual {tuple(residual.shape)} {residual.dtype} contiguous={residual.is_contiguous()} vs output {(images, hout, wout, cout)} {x.dtype}"
         ld_res = cout
     if rowbias is not None:
         assert rowbias.dtype == torch.float32 and rowbias.dim() == 2 and rowbias.shape[1] == cout and rows_per_group > 0

@@ -51,3 +51,7 @@ def test_pipeline_uses_builtin_canny():
     rgb[:, 8:] = 255
     out = pipe.prepare_controlnet_input_image("lllyasviel/control_v11p_sd15_canny", Image.fromarray(rgb))
     assert np.asarray(out).max() == 255 and np.asarray(out).shape == (16, 16, 3)
+    # tensors are control images that are already preprocessed (bench.py, the pipeline tests): never annotated
+    import torch
+    t = torch.rand(3, 16, 16)
+    assert pipe.prepare_controlnet_input_image("lllyasviel/control_v11p_sd15_canny", t) is t
