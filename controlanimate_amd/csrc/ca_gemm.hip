@@ -52,7 +52,8 @@ struct GemmKParams {
 
 constexpr int BK = 64;
 #ifndef CA_GEMM_ABLATE
-#define CA_GEMM_ABLATE 0  // timing experiments only: 1 = no MFMA / fragment reads (DMA + barriers only), 2 = no DMA after tile 0
+#define CA_GEMM_ABLATE 0  // timing experiments only: 1 = no MFMA / fragment reads (DMA + barriers only), 2 = no DMA after tile 0,
+                          // 3 = 2 + one barrier per tile, 4 = 2 + fragments read once (MFMA + barriers only), 5 = 2 + no barriers
 #endif
 
 // Tile order inside an XCD's contiguous id range: groups of GROUP_M row-tiles are swept column by
@@ -380,7 +381,8 @@ constexpr unsigned DMA_OOB = 0xFFFFFFF0u;  // beyond any descriptor size we acce
 //           then a raw s_barrier: DMA transfers stay in flight across barriers
 //           (cdna_hip_programming.md "Pipelining across barriers").  All LDS is one array.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF, int KT = 64>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (NBUF * KT == 64 ? (BN > 128 ? 3 : 4) : 2) * 4 / (WAVES_M * WAVES_N))
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
+                             ((BM / WAVES_M) * (BN / WAVES_N) > 64 * 80 ? 2 : (NBUF * KT == 64 ? (BN > 128 ? 3 : 4) : 2)) * 4 / (WAVES_M * WAVES_N))
 void k_gemm_dma(GemmKParams p) {
   // KT = K elements per LDS stage: 64 (one 128-byte row per tile row) or 32 with NBUF = 2 -- the same 32 KB
   // as one 64-wide stage, so 4 blocks still share a CU, but each block also prefetches its own next stage
@@ -516,10 +518,17 @@ void k_gemm_dma(GemmKParams p) {
 #pragma unroll
     for (int s = 0; s < KT / 32; ++s) {
       u32x4 fa[TM], fb[TN];
+      if (CA_GEMM_ABLATE == 4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = (u32x4){(unsigned)tid, 1u, 2u, 3u};
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = (u32x4){(unsigned)lane, 5u, 6u, 7u};
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[i] = ld16(sa + lds_at(wm * TM * 16 + i * 16 + l15, s * 4 + g));
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = ld16(sb + lds_at(wn * TN * 16 + j * 16 + l15, s * 4 + g));
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -530,10 +539,10 @@ void k_gemm_dma(GemmKParams p) {
     // single LDS buffer (32 KB for 128x128): two barriers per tile, but 3 blocks per CU -- the
     // other resident blocks' MFMA phases cover this block's transfer latency
     for (int t = 0; t < nt; ++t) {
-      if (CA_GEMM_ABLATE != 2 || t == 0) stage(t_first + t, 0);
-      __syncthreads();
+      if (CA_GEMM_ABLATE < 2 || t == 0) stage(t_first + t, 0);
+      if (CA_GEMM_ABLATE != 5 || t == 0) __syncthreads();
       compute(0);
-      __syncthreads();
+      if (CA_GEMM_ABLATE != 3 && CA_GEMM_ABLATE != 5) __syncthreads();
     }
   } else if (NBUF == 2) {
     stage(t_first, 0);
@@ -668,6 +677,12 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   // +4..8% on 8192x10240x1280 and 32768x5120x640; neutral or negative on K = 320 and on the convolutions)
   static const int big_env = getenv("CA_GEMM_BIG") ? atoi(getenv("CA_GEMM_BIG")) : -1;
   const bool big = big_env == 1 || (big_env < 0 && MODE == 0 && p.n >= 5120 && kc >= 640);
+  if (dma && big_env == 2 && p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 256) * (p.n / 128) >= 256) {
+    // experiment: 4 waves x (128 x 64) per wave -- 12 instead of 16 fragment reads per 32 MFMAs, 2 blocks per CU
+    const dim3 grid(ceil_div_i(p.m, 256) * (p.n / 128));
+    hipLaunchKernelGGL((k_gemm_dma<DT, 256, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
+    return CA_OK;
+  }
   if (dma && big && p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 256) * (p.n / 128) >= 512) {
     // 256x128 tiles, 8 waves: 85 instead of 64 flop per byte moved L2 -> LDS, same 4 waves per SIMD
     const dim3 grid(ceil_div_i(p.m, 256) * (p.n / 128));
