@@ -62,11 +62,48 @@ def randomize_zero_init_(model, std=0.02, seed=0):
             p.data.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
 
 
-def tile_name(m: int, n: int) -> str:
-    """Mirrors launch_gemm() in csrc/ca_gemm.hip: 128x128 block tile unless N % 128 != 0 or the grid
-    would have fewer than 512 blocks."""
-    wide = n % 128 == 0 and ((m + 127) // 128) * ((n + 127) // 128) >= 512
+def tile_name(m: int, n: int, k: int, conv: bool) -> str:
+    """Mirrors launch_gemm() / splitk_plan() in csrc/ca_gemm.hip (DMA path, default knobs): which k_gemm_dma
+    instantiation a launch runs.  The label is the BMxBN block tile (+ `_splitk` for the slab schedule)."""
+    def cdiv(a, b):
+        return (a + b - 1) // b
+    if k % 64:  # register-staged fallback kernel (conv_in, hint embedding)
+        wide = n % 128 == 0 and cdiv(m, 128) * cdiv(n, 128) >= 512
+        return "reg_128x128" if wide else "reg_128x64"
+    if conv and n % 128 == 0 and cdiv(m, 128) * (n // 128) < 384 and k // 64 >= 48:
+        return "128x128_splitk"
+    if (not conv) and n >= 5120 and k >= 640 and n % 128 == 0 and cdiv(m, 256) * (n // 128) >= 512:
+        return "256x128"
+    wide = n % 128 == 0 and cdiv(m, 128) * cdiv(n, 128) >= 512
+    if not wide and n % 160 == 0 and cdiv(m, 128) * (n // 160) >= 512:
+        return "128x160"
     return "128x128" if wide else "128x64"
+
+
+def rocprof_kernel_name(family: str, dtype: str) -> str:
+    """The demangled kernel name rocprofv3 reports for a family label (profiles/*kernel_stats.csv)."""
+    op, tile = family.split("_", 1)
+    if tile.startswith("reg_"):
+        return ""
+    dt = 1 if dtype == "fp16" else 0
+    bm, bn = tile.replace("_splitk", "").split("x")
+    waves = "4, 2" if tile == "256x128" else ("4, 1" if tile == "128x64" else "2, 2")
+    return f"k_gemm_dma<{dt}, {bm}, {bn}, {waves}, {1 if op == 'conv3x3' else 0}, "
+
+
+def pmc_traffic(kernel_prefix: str):
+    """HBM-side bytes per launch of a kernel from the committed PMC summary (profiles/round1_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when the summary has no entry."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+    if not kernel_prefix or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        table = json.load(fh)["kernels"]
+    for name, row in table.items():
+        if name.startswith(kernel_prefix):
+            return row["hbm_bytes_per_launch"]
+    return None
 
 
 class KernelTimer:
@@ -91,7 +128,7 @@ class KernelTimer:
             out = gemm0(a, w, **kw)
             e.record()
             m, n, k = a.shape[0], w.shape[0], w.shape[1]
-            timer.records.append((f"gemm_{tile_name(m, n)}", 2.0 * m * n * k, s, e, (m, n, k)))
+            timer.records.append((f"gemm_{tile_name(m, n, k, False)}", 2.0 * m * n * k, s, e, (m, n, k)))
             return out
 
         def conv3x3(x, w, **kw):
@@ -103,7 +140,7 @@ class KernelTimer:
             e.record()
             n = w.shape[0]
             mrows = out.shape[0] * out.shape[1] * out.shape[2]
-            timer.records.append((f"conv3x3_{tile_name(mrows, n)}", 2.0 * mrows * n * 9 * w.shape[3], s, e,
+            timer.records.append((f"conv3x3_{tile_name(mrows, n, 9 * w.shape[3], True)}", 2.0 * mrows * n * 9 * w.shape[3], s, e,
                                   (mrows, n, 9 * w.shape[3])))
             return out
 
@@ -387,8 +424,11 @@ def main():
         if agg:
             dom = max(agg, key=lambda k: agg[k]["ms"])
             d = agg[dom]
-            out["roofline"] = {"bound": "mfma", "kernel": f"k_gemm<{dom}>", "achieved": round(d["tflops"], 2), "peak": PEAK_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+            rname = rocprof_kernel_name(dom, args.dtype)
+            out["roofline"] = {"bound": "mfma", "kernel": f"k_gemm_dma<{dom}>", "rocprof_name": rname + "...>" if rname else None,
+                               "achieved": round(d["tflops"], 2), "peak": PEAK_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(rname),
+                               "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/round1_pmc_traffic.json)",
                                "launches": d["launches"], "avg_launch_us": round(d["avg_us"], 2),
                                "flop_per_launch": round(d["flops"] / d["launches"], 1),
                                "share_of_step_time": round(d["ms"] * 1e-3 / roof_elapsed, 4),

@@ -63,7 +63,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   const int lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
 
-  unsigned bid = blockIdx.x;
+  // XCD-aware order: the q-blocks of one (image, head) -- which all stream the same K/V -- run on ONE XCD and
+  // share its L2 (round-robin dispatch spread them over 8 L2s: 1.39 GB fetched for 252 MB of q|k|v)
+  unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
   const int qb = bid % p.qblocks;
   bid /= p.qblocks;
   const int head = bid % p.heads;
@@ -378,7 +380,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   const int lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
 
-  unsigned bid = blockIdx.x;
+  // XCD-aware order: the q-blocks of one (image, head) -- which all stream the same K/V -- run on ONE XCD and
+  // share its L2 (round-robin dispatch spread them over 8 L2s: 1.39 GB fetched for 252 MB of q|k|v)
+  unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
   const int qb = bid % p.qblocks;
   bid /= p.qblocks;
   const int head = bid % p.heads;
