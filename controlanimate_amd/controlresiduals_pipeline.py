@@ -105,17 +105,22 @@ class MultiControlNetResidualsPipeline:
         side = getattr(self, "_side_stream", None)
         if side is None or side.device != dev:
             side = self._side_stream = torch.cuda.Stream(device=dev)
+        # (inside a hipGraph capture the fork/join below become graph edges; the allocator's cross-stream
+        # bookkeeping is not needed there -- the graph's private pool outlives every replay)
+        capturing = torch.cuda.is_current_stream_capturing()
         side.wait_stream(main)  # x_nhwc (and on the first call the weights) were produced on `main`
         with torch.cuda.stream(side):
             down, mid = self.residuals_nhwc(x_nhwc, t, controlnet_prompt_embeds, guess_mode)
             done = side.record_event()
-        x_nhwc.record_stream(side)
+        if not capturing:
+            x_nhwc.record_stream(side)
 
         def join():
             cur = torch.cuda.current_stream(dev)
             cur.wait_event(done)
-            for r in (*down, mid):
-                r.record_stream(cur)  # allocated on `side`, read on `cur`
+            if not capturing:
+                for r in (*down, mid):
+                    r.record_stream(cur)  # allocated on `side`, read on `cur`
             return down, mid
 
         return join

@@ -1,0 +1,50 @@
+"""hipGraph capture of one denoise step (ControlNet stack on the second stream + UNet3D) replays bit-identically
+to the eager launches (bench.py --graph; the fork/join of residuals_nhwc_async become graph edges)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SMALL = (64, 128, 256, 256)
+
+
+def test_graph_replay_equals_eager():
+    from controlanimate_amd.configs import controlnet_config, unet_config
+    from controlanimate_amd.controlnet import ControlNetModel
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.unet import UNet3DConditionModel
+    from oracle.controlnet import ControlNetConfig, init_controlnet_weights
+    from oracle.unet3d import UNet3DConfig, init_unet3d_weights
+    unet = UNet3DConditionModel.from_config(unet_config("v2", block_out_channels=SMALL))
+    unet.load_state_dict(init_unet3d_weights(UNet3DConfig.v2(block_out_channels=SMALL), seed=41))
+    net = ControlNetModel.from_config(controlnet_config(block_out_channels=SMALL))
+    net.load_state_dict(init_controlnet_weights(ControlNetConfig(block_out_channels=SMALL), seed=42))
+    unet.to(DEV).prepare(DEV)
+    net.to(DEV).prepare(DEV)
+    f, hw = 8, 16
+    g = torch.Generator().manual_seed(3)
+    cn = MultiControlNetResidualsPipeline(["c"], [0.9], use_lcm=False, controlnets=[net], device=DEV)
+    cn.prep_control_images([h for h in torch.rand(f, 3, 8 * hw, 8 * hw, generator=g)], do_classifier_free_guidance=True, guess_mode=False)
+    prompt = (torch.randn(2, 77, 768, generator=g) * 0.5).to(DEV)
+    x_static = torch.empty(2 * f, hw, hw, unet.conv_in.cin_pad, device=DEV, dtype=torch.float16)
+    t_static = torch.zeros(1, device=DEV)
+
+    def model_eps():
+        down = cn.residuals_nhwc_async(x_static, t_static, prompt, False)
+        return unet.forward_nhwc(x_static, 2, f, t_static, prompt, down, None)
+
+    xs = [torch.randn(x_static.shape, generator=g).half().to(DEV) for _ in range(2)]
+    x_static.copy_(xs[0]); t_static.fill_(500.0)
+    model_eps()  # warm caches / allocator
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        eps_g = model_eps()
+    for x, t in ((xs[0], 500.0), (xs[1], 120.0), (xs[0], 500.0)):
+        x_static.copy_(x); t_static.fill_(t)
+        gr.replay()
+        torch.cuda.synchronize()
+        got = eps_g.clone()
+        ref = model_eps()
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all() and torch.equal(got, ref)
