@@ -48,3 +48,40 @@ def test_graph_replay_equals_eager():
         ref = model_eps()
         torch.cuda.synchronize()
         assert torch.isfinite(got).all() and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("scenario", ["lcm_cfg_controlnet", "native_lcm_guess"])
+def test_pipeline_hip_graph_option_is_bit_identical(scenario):
+    """ControlAnimationPipeline(use_hip_graph=True): eager step 0, captured replay afterwards == all-eager."""
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+    from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.schedulers import get_scheduler
+    from tests.test_pipeline_gpu import build
+    native = scenario == "native_lcm_guess"
+    ucfg, uw, unet, ccfg, cws, nets = build("v2", seed=51, n_controlnets=1, **({"time_cond_proj_dim": 256} if native else {}))
+    f, hw = 8, 8
+    g = torch.Generator().manual_seed(9)
+    pos, neg = torch.randn(1, 77, 768, generator=g) * 0.5, torch.randn(1, 77, 768, generator=g) * 0.5
+    hints = torch.rand(f, 3, 8 * hw, 8 * hw, generator=g)
+    lat_in = torch.randn(1, 4, f, hw, hw, generator=g) * 0.8
+    outs = []
+    for use_graph in (False, True):
+        sched = None if native else get_scheduler("LCMScheduler", **NOISE_SCHEDULER_KWARGS)
+        pipe = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched).to(DEV)
+        pipe.use_hip_graph = use_graph
+        cn = MultiControlNetResidualsPipeline(["n0"], [0.8], use_lcm=native, controlnets=nets, device=DEV)
+        torch.manual_seed(3)
+        steps = []
+        out = pipe(video_length=f, input_frames=None, height=8 * hw, width=8 * hw, num_inference_steps=4, strength=0.5 if native else 1.0,
+                   guidance_scale=7.5 if native else 1.3, generator=torch.Generator(device="cpu").manual_seed(3),
+                   multicontrolnetresiduals_pipeline=cn, prompt_embeds=pos, negative_prompt_embeds=neg, use_lcm=native,
+                   guess_mode=native, input_latents=lat_in, control_images={"n0": [h for h in hints]}, output_type="latent",
+                   callback=lambda i, t, l: steps.append(l.clone())).videos
+        torch.cuda.synchronize()
+        assert pipe.graph_replays == (len(steps) - 1 if use_graph else 0)  # the capture really happened
+        outs.append((out.clone(), steps))
+    assert len(outs[0][1]) == len(outs[1][1]) >= 3
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.isfinite(outs[0][0]).all()
