@@ -368,7 +368,11 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
 //     dv (semantics probed on MI355X: tools/probe_tr.hip).  Two reads (keys 4g.. and 16+4g..) give the 8
 //     keys of the fragment in exactly the order the P^T fragment holds them.
 //   * two LDS buffers, the next tile's DMA is issued before the MFMA phase; one barrier per tile.
-template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool SR>
+// FOLD (needs a free 16-byte pad chunk in the K tile too, i.e. head_dim + 8 <= 32*DK32): the softmax argument comes out
+// of the QK^T MFMA ready-made.  Q is pre-multiplied by scale*log2(e) (fp32 multiply, one rounding), column head_dim of
+// every K row holds 1 and the matching k-slot of the Q fragment holds -mref (the quantised reference maximum of that
+// query), so S' = s*scale*log2(e) - mref and p = 2^S' with no per-score VALU besides the v_exp itself.
+template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool SR, bool FOLD>
 __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   constexpr int ROW = 64;                 // LDS row length (elements): head_dim <= 64
   constexpr int KT = KB / 16, KC = KB / 32;
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
     for (int i = tid; i < 2 * KB; i += NW * 64) {
       const int buf = i / KB, r = i - buf * KB;
       st16(smem + buf * TILE + KB * ROW + r * ROW + ((cs ^ ((r >> 1) & 7)) << 3), ones4);
+      if (FOLD) smem[buf * TILE + r * ROW + ((cs ^ ((r >> 1) & 7)) << 3)] = (u16)(one2 & 0xffffu);  // K[r][head_dim] = 1
     }
   }
 
@@ -425,8 +430,22 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
     for (int kc = 0; kc < DK32; ++kc) {
       const int d = kc * 32 + g * 8;
       qf[t][kc] = (qi < p.nq && d < p.head_dim) ? ld16(qp + (int64_t)qi * p.q_row + d) : zero4;
+      if (FOLD) {
+        float f[8];
+        unpack8<DT>(qf[t][kc], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= p.scale_log2;
+        qf[t][kc] = pack8<DT>(f);
+      }
     }
   }
+  // FOLD: the lanes of row group fold_g hold k-slot head_dim of k32 chunk fold_kc, element 0 of their fragment
+  const int fold_kc = p.head_dim >> 5, fold_g = (p.head_dim & 31) >> 3;
+  auto set_qref = [&](int t, float mnew) {
+#pragma unroll
+    for (int kc = 0; kc < DK32; ++kc)
+      if (kc == fold_kc && g == fold_g) qf[t][kc][0] = (qf[t][kc][0] & 0xffff0000u) | (unsigned)Elem<DT>::from_f(-mnew);
+  };
 
   // DMA lane assignment: 8 rows x 8 chunks per wave instruction
   const int r8 = lane >> 3, cpos = lane & 7;
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   float mref[QT], lrun[QT];  // mref: reference maximum, already multiplied by scale*log2(e)
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    mref[t] = -INFINITY;
+    mref[t] = FOLD ? 0.f : -INFINITY;  // FOLD: the Q slot starts at -0; tile 0 always re-bases
     lrun[t] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DV16; ++dt) oacc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -501,9 +520,11 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
     // the result independent of the reference point).  No cross-lane traffic on the common path: each
     // lane compares its own 16 scores with mref, the ballot ORs the lanes.
     float mloc[QT];
-    bool grow = false;
+    bool grow = FOLD && iter == 0;
+    float shift[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
+      shift[t] = 0.f;
       if (TAIL) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -520,12 +541,23 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
         else m = vmax2(m, sacc[t][kt][3]);
       }
       mloc[t] = m;
-      grow |= m * p.scale_log2 > mref[t] + 8.0f;
+      if (FOLD) grow |= m > 8.0f;  // scores are already relative to mref
+      else grow |= m * p.scale_log2 > mref[t] + 8.0f;
     }
-    if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+    const bool rebase = __builtin_amdgcn_ballot_w64(grow) != 0ull;
+    if (rebase) {
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        const float mnew = fmaxf(mref[t], rowgroup_max(mloc[t]) * p.scale_log2);
+        float mnew;
+        if (FOLD) {
+          const float mx = rowgroup_max(mloc[t]);
+          // the new reference must be representable in the activation type: it travels in the Q fragment
+          mnew = Elem<DT>::to_f(Elem<DT>::from_f(mref[t] + (iter == 0 ? mx : fmaxf(mx, 0.f))));
+          shift[t] = mnew - mref[t];
+          set_qref(t, mnew);
+        } else {
+          mnew = fmaxf(mref[t], rowgroup_max(mloc[t]) * p.scale_log2);
+        }
         const float alpha = __builtin_amdgcn_exp2f(mref[t] - mnew);
         mref[t] = mnew;
         if (!SR) lrun[t] *= alpha;
@@ -537,11 +569,25 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      const float nmc = -mref[t];
+      if (FOLD) {
+        if (rebase) {  // this tile's scores are still relative to the previous reference
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+          for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
+            for (int r = 0; r < 4; ++r) sacc[t][kt][r] = __builtin_amdgcn_exp2f(sacc[t][kt][r] - shift[t]);
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[t][kt][r] = __builtin_amdgcn_exp2f(sacc[t][kt][r]);
+        }
+      } else {
+        const float nmc = -mref[t];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[t][kt][r], p.scale_log2, nmc));
+      }
       if (!SR) {
         float psum = 0.f;
 #pragma unroll
@@ -642,8 +688,11 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
       // the ones column needs a free, 16-byte aligned pad chunk inside the last 16-wide dv tile
       static const int sr_env = getenv("CA_ATTN_SR") ? atoi(getenv("CA_ATTN_SR")) : 1;
       const bool sr = sr_env && p.head_dim % 8 == 0 && p.head_dim / 16 == DV16 - 1;
-      if (sr) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, false>), grid, dim3(256), 0, st, p);
+      static const int fold_env = getenv("CA_ATTN_FOLD") ? atoi(getenv("CA_ATTN_FOLD")) : 1;
+      const bool fold = sr && fold_env && p.head_dim + 8 <= DK32 * 32;
+      if (fold) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, true>), grid, dim3(256), 0, st, p);
+      else if (sr) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, false>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, false, false>), grid, dim3(256), 0, st, p);
       return;
     }
     static const int var_env = getenv("CA_ATTN_VAR") ? atoi(getenv("CA_ATTN_VAR")) : 0;  // experiments (d <= 48 only)
