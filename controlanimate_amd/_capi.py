@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcontrolanimate_hip.so")
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CAHipUnavailable(RuntimeError):
@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("rows_per_group", C.c_int32),
         ("alpha", C.c_float), ("post_scale", C.c_float),
         ("act", C.c_int32), ("geglu", C.c_int32), ("out_f32", C.c_int32), ("dtype", C.c_int32),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
     ]
 
 
@@ -67,7 +68,7 @@ class LayerNormArgs(C.Structure):
         ("pos", C.c_void_p),
         ("rows", C.c_int64),
         ("c", C.c_int32), ("rows_per_frame", C.c_int32), ("frames", C.c_int32),
-        ("eps", C.c_float), ("dtype", C.c_int32),
+        ("eps", C.c_float), ("dtype", C.c_int32), ("stats", C.c_void_p),
     ]
 
 

@@ -31,6 +31,8 @@ struct GemmKParams {
   void* c;
   const float* bias;
   const float* rowbias;
+  const float* ln_stats;   // [M][2] (mean, rstd) of the A rows: LayerNorm folded into this GEMM (see ca_gemm_args)
+  const float* ln_colsum;  // [N] sum_k W'[n][k]
   const u16* res;
   int64_t lda, lda2, ldc, ld_res, ld_rowbias;
   unsigned a_bytes, a2_bytes, w_bytes;  // buffer-descriptor sizes for the LDS-DMA variant
@@ -168,6 +170,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
       if (n < p.n) {
+        if (p.ln_stats && m < p.m) {  // LN(x) W'^T = rstd * (x W'^T - mean * colsum(W'))
+          const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + (int64_t)m * 2);
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = st.y * (v[r] - st.x * cs[r]);
+        }
         if (p.bias) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
@@ -744,6 +752,10 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   p.c = a->c;
   p.bias = a->bias;
   p.rowbias = a->rowbias;
+  p.ln_stats = a->ln_stats;
+  p.ln_colsum = a->ln_colsum;
+  CA_REQUIRE(!a->ln_stats == !a->ln_colsum, "ca_gemm: ln_stats and ln_colsum go together");
+  CA_REQUIRE(!a->ln_stats || (a->n >= 8 && a->k2 == 0), "ca_gemm: the folded LayerNorm needs N >= 8 and a single A source");
   p.res = (const u16*)a->residual;
   p.lda = a->lda;
   p.lda2 = a->lda2;

@@ -339,6 +339,7 @@ struct LnParams {
   const float* gamma;
   const float* beta;
   const float* pos;
+  float* stats;  // non-NULL: write (mean, rstd) per row instead of the normalised output
   int64_t rows;
   int c;
   int rows_per_frame, frames;
@@ -419,6 +420,14 @@ __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
     }
 #pragma unroll
     for (int r = 0; r < LN_RPW; ++r) rstd[r] = rsqrtf(rstd[r] * inv_c + p.eps);
+    if (p.stats) {  // statistics for a LayerNorm folded into the following GEMM (ca_gemm_args.ln_stats)
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < LN_RPW; ++r)
+          if (row0 + r < p.rows) *reinterpret_cast<float2*>(p.stats + (row0 + r) * 2) = make_float2(mean[r], rstd[r]);
+      }
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
       if (!cok[k]) continue;
@@ -520,7 +529,8 @@ extern "C" int ca_groupnorm_apply(const ca_groupnorm_args* a, void* stream) {
 
 extern "C" int ca_layernorm(const ca_layernorm_args* a, void* stream) {
   CA_REQUIRE(a != nullptr, "ca_layernorm: null args");
-  CA_REQUIRE(a->x && a->y && a->gamma && a->beta, "ca_layernorm: null operand");
+  CA_REQUIRE(a->x && (a->stats || (a->y && a->gamma && a->beta)), "ca_layernorm: null operand");
+  CA_REQUIRE(!a->stats || !a->pos, "ca_layernorm: stats mode has no positional table");
   CA_REQUIRE(a->rows > 0, "ca_layernorm: rows");
   CA_REQUIRE(a->c > 0 && a->c % 8 == 0 && a->c <= 64 * 8 * LN_MAX_SLOTS, "ca_layernorm: C=%d must be a multiple of 8 and <= %d", a->c, 64 * 8 * LN_MAX_SLOTS);
   CA_REQUIRE(!a->pos || (a->rows_per_frame > 0 && a->frames > 0), "ca_layernorm: pos needs rows_per_frame/frames");
@@ -531,6 +541,7 @@ extern "C" int ca_layernorm(const ca_layernorm_args* a, void* stream) {
   p.gamma = a->gamma;
   p.beta = a->beta;
   p.pos = a->pos;
+  p.stats = a->stats;
   p.rows = a->rows;
   p.c = a->c;
   p.rows_per_frame = a->rows_per_frame > 0 ? a->rows_per_frame : 1;

@@ -44,8 +44,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
          bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
          rows_per_group: int = 0, residual: Optional[torch.Tensor] = None, alpha: float = 1.0,
          post_scale: float = 1.0, act: int = ACT_NONE, geglu: bool = False, out_f32: bool = False,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M, N] = epilogue(cat(a, a2)[M, K] @ w[N, K]^T); see ca_gemm in the header."""
+         out: Optional[torch.Tensor] = None, ln=None) -> torch.Tensor:
+    """out[M, N] = epilogue(cat(a, a2)[M, K] @ w[N, K]^T); see ca_gemm in the header.
+    ln = (row_stats(a), colsum(w) fp32 [N]): LayerNorm of `a` folded in (w, bias packed accordingly)."""
     _req_cuda(a, w, a2, bias, rowbias, residual, out)
     assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous()
     m, k1 = a.shape
@@ -72,6 +73,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
                     m=m, n=n, k1=k1, k2=k2, rows_per_group=rows_per_group, alpha=alpha,
                     post_scale=post_scale, act=act, geglu=int(geglu), out_f32=int(out_f32),
                     dtype=dt_code(a.dtype))
+    if ln is not None:
+        st, cs = ln
+        assert st.dtype == torch.float32 and st.shape == (m, 2) and st.is_contiguous() and cs.dtype == torch.float32 and cs.numel() == n
+        args.ln_stats, args.ln_colsum = _p(st), _p(cs)
     check(lib().ca_gemm(C.byref(args), _stream()), "ca_gemm")
     return out
 
@@ -156,6 +161,19 @@ def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, pos:
                          rows_per_frame=rows_per_frame, frames=frames, eps=eps, dtype=dt_code(x.dtype))
     check(lib().ca_layernorm(C.byref(args), _stream()), "ca_layernorm")
     return y
+
+
+def row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """(mean, rstd) of every row of x [rows, C] as fp32 [rows, 2]: the statistics of a LayerNorm that is
+    folded into the following GEMM (gemm(..., ln=(stats, colsum)))."""
+    _req_cuda(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    rows, c = x.shape
+    st = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    args = LayerNormArgs(x=_p(x), y=None, gamma=None, beta=None, pos=None, rows=rows, c=c, rows_per_frame=1, frames=1,
+                         eps=eps, dtype=dt_code(x.dtype), stats=_p(st))
+    check(lib().ca_layernorm(C.byref(args), _stream()), "ca_layernorm(stats)")
+    return st
 
 
 def attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, *, q_off: int, k_off: int,

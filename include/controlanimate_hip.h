@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 3
+#define CA_ABI_VERSION 4
 
 /* element types */
 #define CA_BF16 0
@@ -94,6 +94,15 @@ typedef struct ca_gemm_args {
   int32_t geglu;        /* 0/1           */
   int32_t out_f32;      /* 0/1           */
   int32_t dtype;        /* CA_BF16/CA_F16 */
+  /* LayerNorm folded into the GEMM (nn.LayerNorm + the Linear it feeds: animatediff/models/attention.py:
+   * 214-237,263-288 norm1/2/3, motion_module.py:203-224 norms / ff_norm):  with W' = W diag(gamma) packed as
+   * `w` and bias' = W beta + b as `bias`,
+   *     LN(x) W^T + b = rstd * (x W'^T - mean * colsum(W')) + bias'
+   * `ln_stats` [M][2] = (mean, rstd) per A row (ca_layernorm with `stats` set), `ln_colsum` [N] = the row sums
+   * of W' as packed (both fp32, both or neither).  Applied to the accumulator before bias/rowbias.  A is then the
+   * un-normalised tensor: the normalised copy is never written or re-read. */
+  const float* ln_stats;
+  const float* ln_colsum;
 } ca_gemm_args;
 int ca_gemm(const ca_gemm_args* args, void* stream);
 
@@ -193,6 +202,8 @@ typedef struct ca_layernorm_args {
   int32_t rows_per_frame, frames;
   float eps;
   int32_t dtype;
+  float* stats;         /* non-NULL: write (mean, rstd) per row to stats[2*row ..] and nothing else
+                           (y, gamma, beta, pos unused): input of ca_gemm_args.ln_stats */
 } ca_layernorm_args;
 int ca_layernorm(const ca_layernorm_args* args, void* stream);
 

@@ -327,6 +327,41 @@ def test_attention_causal(images, tokens, heads, d, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k,geglu,rb", [(300, 960, 320, False, False), (4096, 2560, 320, True, False), (512, 640, 640, False, True),
+                                             (77, 1280, 1280, False, False)])
+def test_gemm_with_folded_layernorm(m, n, k, geglu, rb, dtype):
+    """LN(x) W^T + b == rstd * (x W'^T - mean * colsum(W')) + (W beta + b), W' = W diag(gamma):
+    ca_layernorm(stats) + ca_gemm(ln_stats, ln_colsum) against LayerNorm -> Linear in fp32."""
+    k_ = _k()
+    x = (rnd(m, k, dtype=torch.float32, seed=61) * 1.7 + 0.8).to(dtype)     # non-zero mean: the correction term matters
+    w = rnd(n, k, dtype=torch.float32, scale=k ** -0.5, seed=62)
+    b = rnd(n, dtype=torch.float32, seed=63)
+    gamma, beta = 1 + 0.2 * rnd(k, dtype=torch.float32, seed=64), 0.3 * rnd(k, dtype=torch.float32, seed=65)
+    rowbias = rnd(4, n, dtype=torch.float32, seed=66) if rb else None
+    y = F.linear(F.layer_norm(x.float(), (k,), gamma, beta, 1e-5), w, b)
+    if rb:
+        y = y + rowbias.repeat_interleave(m // 4, 0)
+    if geglu:
+        h, g = y.chunk(2, -1)
+        y = h * F.gelu(g)
+    wf = (w * gamma[None, :])
+    bf = w @ beta + b
+    if geglu:
+        from controlanimate_amd.layers import geglu_interleave
+        wf, bf = geglu_interleave(wf), geglu_interleave(bf)
+    wp = wf.to(dtype)
+    cs = wp.float().sum(1)
+    xd = x.to(DEV)
+    st = k_.row_stats(xd, 1e-5)
+    ref_st = torch.stack([x.float().mean(1), (x.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1)
+    assert torch.allclose(st.cpu(), ref_st, rtol=2e-4, atol=2e-5)
+    out = k_.gemm(xd, wp.to(DEV), bias=bf.to(DEV), geglu=geglu, ln=(st, cs.to(DEV)),
+                  rowbias=None if rowbias is None else rowbias.to(DEV), rows_per_group=m // 4 if rb else 0)
+    torch.cuda.synchronize()
+    close(out, y, dtype, f"gemm_ln({m},{n},{k})")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("act", [2, 3])
 def test_gemm_clip_activations(act, dtype):
     """CA_ACT_QUICK_GELU (x * sigmoid(1.702 x)) and CA_ACT_GELU (erf) epilogues."""
