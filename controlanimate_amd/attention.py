@@ -20,7 +20,7 @@ from torch import nn
 from . import kernels as K
 from .attention_processor import Attention, AttnProcessor2_0
 from .context import ExecCtx
-from .layers import HipConv1x1, HipGroupNorm, HipLayerNorm, HipLinear, WeightArena, _f32, geglu_interleave
+from .layers import HipConv1x1, HipGroupNorm, HipLayerNorm, HipLinear, LnFold, WeightArena, _f32, geglu_interleave, ln_fold_enabled
 
 
 class GEGLU(nn.Module):
@@ -47,12 +47,23 @@ class FeedForward(nn.Module):
         inner = int(dim * mult)
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Identity(), HipLinear(inner, dim_out or dim)])
 
-    def pack(self, arena, dtype):
-        self.net[0].pack(arena, dtype)
+    def pack(self, arena, dtype, fold_ln=None):
+        """fold_ln: the LayerNorm in front of the feed-forward; it is folded into the GEGLU projection."""
+        self.fold = None
+        if fold_ln is not None and ln_fold_enabled():
+            self.fold = LnFold(arena, dtype, fold_ln, [self.net[0].proj], geglu=True)
+        else:
+            self.net[0].pack(arena, dtype)
         self.net[2].pack(arena, dtype)
 
     def run(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return self.net[2].run(self.net[0].run(x), residual=residual)
+        """With a folded LayerNorm `x` is the UN-normalised input."""
+        fold = getattr(self, "fold", None)
+        if fold is not None:
+            h = K.gemm(x, fold.w.t, bias=fold.b.t, geglu=True, ln=(K.row_stats(x, fold.eps), fold.cs.t))
+        else:
+            h = self.net[0].run(x)
+        return self.net[2].run(h, residual=residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -82,21 +93,34 @@ class BasicTransformerBlock(nn.Module):
         self.processor = processor
 
     def pack(self, arena, dtype):
-        for m in (self.attn1, self.norm1, self.attn2, self.norm2, self.ff, self.norm3):
-            if m is not None:
-                m.pack(arena, dtype)
+        # The three LayerNorms are folded into the projections they feed (LnFold: gamma into the weights, mean /
+        # rstd in the GEMM epilogue): the normalised copy of the residual stream is never written or re-read.
+        # An attention with a user-supplied processor keeps the plain LayerNorm -> processor protocol.
+        self.attn1.pack(arena, dtype, fold_ln=self.norm1)
+        self.norm1.pack(arena, dtype)
+        if self.attn2 is not None:
+            self.attn2.pack(arena, dtype, fold_ln=self.norm2)
+            self.norm2.pack(arena, dtype)
+        self.ff.pack(arena, dtype, fold_ln=self.norm3)
+        self.norm3.pack(arena, dtype)
 
     def forward(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
         """x: [images, tokens, C]."""
         B, N, C = x.shape
-        n1 = self.norm1.run(x.view(B * N, C)).view(B, N, C)
-        x = self.attn1(n1, residual=x)
+        if self.attn1.fold is not None:
+            x = self.attn1(x, residual=x, ln=(K.row_stats(x.view(B * N, C), self.norm1.eps), self.attn1.fold))
+        else:
+            x = self.attn1(self.norm1.run(x.view(B * N, C)).view(B, N, C), residual=x)
         if self.attn2 is not None:
-            n2 = self.norm2.run(x.view(B * N, C)).view(B, N, C)
-            x = self.attn2(n2, encoder_hidden_states=ctx.ehs, residual=x, frames_per_kv=ctx.frames_per_kv,
-                           kv_mod=ctx.kv_mod, cache=ctx.cache)
+            kw = dict(encoder_hidden_states=ctx.ehs, residual=x, frames_per_kv=ctx.frames_per_kv, kv_mod=ctx.kv_mod, cache=ctx.cache)
+            if self.attn2.fold is not None:
+                x = self.attn2(x, ln=(K.row_stats(x.view(B * N, C), self.norm2.eps), self.attn2.fold), **kw)
+            else:
+                x = self.attn2(self.norm2.run(x.view(B * N, C)).view(B, N, C), **kw)
         x2 = x.view(B * N, C)
-        return self.ff.run(self.norm3.run(x2), residual=x2).view(B, N, C)
+        if self.ff.fold is None:
+            return self.ff.run(self.norm3.run(x2), residual=x2).view(B, N, C)
+        return self.ff.run(x2, residual=x2).view(B, N, C)
 
 
 class Transformer3DModel(nn.Module):

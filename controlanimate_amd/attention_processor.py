@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
-from .layers import HipLinear, WeightArena, pack_concat_rows
+from .layers import HipLinear, LnFold, WeightArena, ln_fold_enabled, pack_concat_rows
 
 
 class AttnProcessor2_0(nn.Module):
@@ -37,14 +37,24 @@ class AttnProcessor2_0(nn.Module):
 
     def __call__(self, attn: "Attention", hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
                  attention_mask=None, temb=None, *, residual: Optional[torch.Tensor] = None, frames_per_kv: int = 1,
-                 kv_mod: int = 0, temporal=None, cache: Optional[dict] = None) -> torch.Tensor:
+                 kv_mod: int = 0, temporal=None, cache: Optional[dict] = None, ln=None) -> torch.Tensor:
+        """ln = (row statistics, LnFold): `hidden_states` is then the UN-normalised tensor and the LayerNorm that
+        precedes this attention is folded into the q / q|k|v projection (built-in processors only)."""
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is not used anywhere on the reference's path")
         B, N, C = hidden_states.shape
         x = hidden_states.reshape(B * N, C)
         res = None if residual is None else residual.reshape(B * N, C)
+        if ln is not None:
+            st, fold = ln
+            if encoder_hidden_states is None and temporal is not None and fold.pe is not None:
+                b, f, n = temporal
+                qkv = K.gemm(x, fold.w.t, bias=fold.b.t, ln=(st, fold.cs.t), rowbias=fold.rowbias(b, f), rows_per_group=n)
+            else:
+                qkv = K.gemm(x, fold.w.t, bias=fold.b.t, ln=(st, fold.cs.t))
         if encoder_hidden_states is None:
-            qkv = K.gemm(x, attn.qkv.t)
+            if ln is None:
+                qkv = K.gemm(x, attn.qkv.t)
             if temporal is not None:
                 b, f, n = temporal
                 o = K.attention_temporal(qkv, b, f, n, attn.heads)
@@ -53,7 +63,7 @@ class AttnProcessor2_0(nn.Module):
         else:
             ctx = encoder_hidden_states
             nb, L, cd = ctx.shape
-            q = K.gemm(x, attn.to_q.w.t)
+            q = qkv if ln is not None else K.gemm(x, attn.to_q.w.t)
             kv = None if cache is None else cache.get(("kv", id(attn)))
             if kv is None:
                 kv = K.gemm(ctx.reshape(nb * L, cd), attn.kv.t)
@@ -132,7 +142,7 @@ class Attention(nn.Module):
         self.to_v = HipLinear(ctx_dim, inner, bias=bias)
         self.to_out = nn.ModuleList([HipLinear(inner, query_dim, bias=True), nn.Identity()])
         self.processor = processor if processor is not None else AttnProcessor2_0()
-        self.qkv = self.kv = None
+        self.qkv = self.kv = self.fold = None
 
     def set_processor(self, processor, _remove_lora: bool = False):
         if isinstance(getattr(self, "processor", None), nn.Module) and not isinstance(processor, nn.Module):
@@ -142,8 +152,18 @@ class Attention(nn.Module):
     def get_processor(self, return_deprecated_lora: bool = False):
         return self.processor
 
-    def pack(self, arena: WeightArena, dtype):
-        if self.is_cross:
+    def builtin_processor(self) -> bool:
+        return type(self.processor) in (AttnProcessor2_0, IPAttnProcessor2_0, CNAttnProcessor2_0)
+
+    def pack(self, arena: WeightArena, dtype, fold_ln=None, pe=None):
+        """fold_ln: the LayerNorm in front of this attention; with a built-in processor it is folded into the
+        query-side projection (LnFold) and the plain copies of those weights are not packed."""
+        self.fold = None
+        if fold_ln is not None and self.builtin_processor() and ln_fold_enabled():
+            self.fold = LnFold(arena, dtype, fold_ln, [self.to_q] if self.is_cross else [self.to_q, self.to_k, self.to_v], pe=pe)
+            if self.is_cross:
+                self.kv = pack_concat_rows(arena, dtype, [self.to_k, self.to_v])
+        elif self.is_cross:
             self.to_q.pack(arena, dtype)
             self.kv = pack_concat_rows(arena, dtype, [self.to_k, self.to_v])
         else:

@@ -157,6 +157,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
     return;
   }
   constexpr int CLD = BN + 8;
+  // folded LayerNorm: this lane's TM row statistics and TN column-sum quads, loaded once
+  float2 ln_st[TM];
+  f32x4 ln_cs[TN];
+  if (p.ln_stats) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * TM * 16 + i * 16 + l15;
+      ln_st[i] = m < p.m ? *reinterpret_cast<const float2*>(p.ln_stats + (int64_t)m * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 16 + j * 16 + g * 4;
+      ln_cs[j] = n < p.n ? *reinterpret_cast<const f32x4*>(p.ln_colsum + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int row = wm * TM * 16 + i * 16 + l15;
@@ -170,11 +185,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
       if (n < p.n) {
-        if (p.ln_stats && m < p.m) {  // LN(x) W'^T = rstd * (x W'^T - mean * colsum(W'))
-          const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + (int64_t)m * 2);
-          const f32x4 cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+        if (p.ln_stats) {  // LN(x) W'^T = rstd * (x W'^T - mean * colsum(W'))
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = st.y * (v[r] - st.x * cs[r]);
+          for (int r = 0; r < 4; ++r) v[r] = ln_st[i].y * (v[r] - ln_st[i].x * ln_cs[j][r]);
         }
         if (p.bias) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);

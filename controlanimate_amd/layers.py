@@ -189,6 +189,54 @@ def pack_concat_bias(arena: WeightArena, mods: Sequence[nn.Module]) -> Packed:
     return arena.add((n,), torch.float32, lambda: torch.cat([_f32(m.bias) for m in mods], 0))
 
 
+def ln_fold_enabled() -> bool:
+    """CA_LN_FOLD=0 keeps LayerNorm as its own kernel (A/B measurements)."""
+    import os
+    return os.environ.get("CA_LN_FOLD", "1") != "0"
+
+
+class LnFold:
+    """Packed operands of `LayerNorm -> Linear(s)` run as ONE ca_gemm on the un-normalised activations
+    (ca_gemm_args.ln_stats): W' = cat(W_i) diag(gamma) [rows GEGLU-interleaved if asked], colsum(W') of the
+    ROUNDED W', bias' = cat(W_i) beta + cat(b_i).  With a positional table `pe` [max_len, K] (temporal
+    attention: (LN(x) + pe) W^T) also the per-frame row bias pe W^T [max_len, N]."""
+
+    def __init__(self, arena: WeightArena, dtype, ln: "HipLayerNorm", mods: Sequence[nn.Module], geglu: bool = False, pe=None):
+        n = sum(m.weight.shape[0] for m in mods)
+        k = mods[0].weight.shape[1]
+        self.eps = ln.eps
+
+        def w_cat():
+            return torch.cat([_f32(m.weight).reshape(m.weight.shape[0], -1) for m in mods], 0)
+
+        def w_fold():
+            w = w_cat() * _f32(ln.weight)[None, :]
+            return geglu_interleave(w) if geglu else w
+
+        def bias():
+            b = w_cat() @ _f32(ln.bias)
+            b = b + torch.cat([_f32(m.bias) if getattr(m, "bias", None) is not None else torch.zeros(m.weight.shape[0], device=m.weight.device) for m in mods], 0)
+            return geglu_interleave(b) if geglu else b
+
+        self.w = arena.add((n, k), dtype, w_fold)
+        self.cs = arena.add((n,), torch.float32, lambda: w_fold().to(dtype).float().sum(1))
+        self.b = arena.add((n,), torch.float32, bias)
+        self.pe = None
+        if pe is not None:
+            self.pe = arena.add((pe.shape[-2], n), torch.float32, lambda: _f32(pe).reshape(pe.shape[-2], k).to(mods[0].weight.device) @ w_cat().to(dtype).float().t())
+        self._rb_cache = {}
+
+    def rowbias(self, b: int, f: int) -> torch.Tensor:
+        """[b*f, N] fp32: row group g = (batch, frame) gets pe[frame] W^T (rows are in (b f n) order)."""
+        if f > self.pe.t.shape[0]:
+            raise ValueError(f"video_length {f} exceeds temporal_position_encoding_max_len {self.pe.t.shape[0]}")
+        key = (b, f, self.pe.t.data_ptr())
+        rb = self._rb_cache.get(key)
+        if rb is None:
+            rb = self._rb_cache[key] = self.pe.t[:f].repeat(b, 1).contiguous()
+        return rb
+
+
 def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
     """[2D, ...] (value rows then gate rows) -> rows (v0, g0, v1, g1, ...)."""
     d = w.shape[0] // 2

@@ -58,8 +58,9 @@ class VersatileAttention(Attention):
         self.pos_encoder = PositionalEncoding(kwargs["query_dim"], max_len=temporal_position_encoding_max_len) \
             if temporal_position_encoding else None
 
-    def pack(self, arena, dtype):
-        super().pack(arena, dtype)
+    def pack(self, arena, dtype, fold_ln=None):
+        pe = self.pos_encoder.pe if (fold_ln is not None and self.pos_encoder is not None) else None
+        super().pack(arena, dtype, fold_ln=fold_ln, pe=pe)
         if self.pos_encoder is not None:
             self.pos_encoder.pack(arena, dtype)
 
@@ -88,16 +89,27 @@ class TemporalTransformerBlock(nn.Module):
         self.ff_norm = HipLayerNorm(dim)
 
     def pack(self, arena, dtype):
-        for m in list(self.attention_blocks) + list(self.norms) + [self.ff, self.ff_norm]:
-            m.pack(arena, dtype)
+        # LayerNorm (+ positional encoding) folded into the q|k|v projection, ff_norm into the GEGLU projection:
+        # (LN(x) + pe) W^T = LN(x) W^T + pe W^T, the second term is a per-frame row bias (LnFold.pe)
+        for attn, norm in zip(self.attention_blocks, self.norms):
+            attn.pack(arena, dtype, fold_ln=norm)
+            norm.pack(arena, dtype)
+        self.ff.pack(arena, dtype, fold_ln=self.ff_norm)
+        self.ff_norm.pack(arena, dtype)
 
     def forward(self, x: torch.Tensor, ctx: ExecCtx, tokens: int) -> torch.Tensor:
         """x: [(b f n), C] rows."""
         rows, C = x.shape
         for attn, norm in zip(self.attention_blocks, self.norms):
-            n = norm.run(x, pos=attn.pos_table(ctx.f), rows_per_frame=tokens, frames=ctx.f)
-            x = attn(n.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens)).view(rows, C)
-        return self.ff.run(self.ff_norm.run(x), residual=x)
+            if attn.fold is not None:
+                x = attn(x.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens),
+                         ln=(K.row_stats(x, norm.eps), attn.fold)).view(rows, C)
+            else:
+                n = norm.run(x, pos=attn.pos_table(ctx.f), rows_per_frame=tokens, frames=ctx.f)
+                x = attn(n.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens)).view(rows, C)
+        if self.ff.fold is None:
+            return self.ff.run(self.ff_norm.run(x), residual=x)
+        return self.ff.run(x, residual=x)
 
 
 class TemporalTransformer3DModel(nn.Module):
