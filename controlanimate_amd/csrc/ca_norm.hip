@@ -460,8 +460,72 @@ __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
   }
 }
 
+// Statistics-only pass (LayerNorm folded into the following GEMM).  Lane mapping as in the GroupNorm kernels:
+// TX = 2^txlog lanes share a row (C/8 = TX * slots chunks), so a wave holds 64/TX rows at once and a row's sum /
+// sum of squares is reduced with log2(TX) shuffle steps -- one pass, 2 rows per lane group per trip, against two
+// 6-step reductions per 4 rows in k_layernorm.  var = E[x^2] - mean^2 in fp32 (C <= 2560 activations: the
+// cancellation error ~1e-7 * mean^2 / var is far below the fp16 rounding of the GEMM operands).
+template <int DT, int txlog>
+__global__ __launch_bounds__(256) void k_ln_stats(LnParams p) {
+  constexpr int TX = 1 << txlog, TY = 256 >> txlog;
+  const int C8 = p.c >> 3;
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> txlog;
+  const float inv_c = 1.0f / (float)p.c;
+  for (int64_t row0 = (int64_t)blockIdx.x * 2 * TY; row0 < p.rows; row0 += (int64_t)gridDim.x * 2 * TY) {
+    const int64_t rows2[2] = {row0 + ty, row0 + TY + ty};
+    u32x4 raw[2][GN_MAX_SLOTS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int c8 = tx + (k << txlog);
+        raw[h][k] = (c8 < C8 && rows2[h] < p.rows) ? ld16(p.x + rows2[h] * p.c + (c8 << 3)) : (u32x4){0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        if ((k << txlog) < C8) {
+          float f[8];
+          unpack8<DT>(raw[h][k], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            s += f[j];
+            ss += f[j] * f[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < TX; off <<= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+      }
+      if (tx == 0 && rows2[h] < p.rows) {
+        const float mean = s * inv_c;
+        const float var = fmaxf(ss * inv_c - mean * mean, 0.f);
+        *reinterpret_cast<float2*>(p.stats + rows2[h] * 2) = make_float2(mean, rsqrtf(var + p.eps));
+      }
+    }
+  }
+}
+
 template <int DT>
 void launch_layernorm(const LnParams& p, hipStream_t st) {
+  if (p.stats && p.c <= GN_MAX_C) {
+    const int txlog = gn_txlog(p.c >> 3);
+    const int ty = 256 >> txlog;
+    int64_t blocks = (p.rows + 2 * ty - 1) / (2 * ty);
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks), block(256);
+    switch (txlog) {
+      case 3: hipLaunchKernelGGL((k_ln_stats<DT, 3>), grid, block, 0, st, p); break;
+      case 4: hipLaunchKernelGGL((k_ln_stats<DT, 4>), grid, block, 0, st, p); break;
+      case 5: hipLaunchKernelGGL((k_ln_stats<DT, 5>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((k_ln_stats<DT, 6>), grid, block, 0, st, p); break;
+    }
+    return;
+  }
   int64_t waves = (p.rows + LN_RPW - 1) / LN_RPW;
   int64_t blocks = (waves + 3) / 4;
   if (blocks > 16384) blocks = 16384;
