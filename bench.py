@@ -166,6 +166,7 @@ class KernelTimer:
         wrap_other("attention_raw", lambda q, k, v, o, **kw: (kw["batches"], kw["heads"], kw["head_dim"], kw["nq"], kw["nk"]))
         wrap_other("group_norm", lambda x, g, b, **kw: tuple(x.shape) + ((kw["x2"].shape[3],) if kw.get("x2") is not None else (0,)))
         wrap_other("layer_norm", lambda x, g, b, **kw: tuple(x.shape))
+        wrap_other("row_stats", lambda x, *a, **kw: tuple(x.shape))
         wrap_other("add_bcast", lambda a, b, out=None: (a.numel(),))
 
     def other_summary(self, top=30):

@@ -172,11 +172,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
       ln_cs[j] = n < p.n ? *reinterpret_cast<const f32x4*>(p.ln_colsum + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
+  // per-row-group bias: when the wave's 16*TM rows fall into ONE group (time-embedding rows of a resnet, the
+  // per-frame positional row bias of a temporal q|k|v projection) its TN quads are loaded once, not per row tile
+  f32x4 rb_q[TN];
+  bool rb_uniform = false;
+  if (p.rowbias) {
+    const int r_first = m0 + wm * TM * 16, r_last = r_first + TM * 16 - 1;
+    rb_uniform = r_last < p.m && r_first / p.rows_per_group == r_last / p.rows_per_group;
+    if (rb_uniform) {
+      const float* base = p.rowbias + (int64_t)(r_first / p.rows_per_group) * p.ld_rowbias;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 16 + j * 16 + g * 4;
+        rb_q[j] = n < p.n ? *reinterpret_cast<const f32x4*>(base + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int row = wm * TM * 16 + i * 16 + l15;
     const int m = m0 + row;
-    const float* rbp = (p.rowbias && m < p.m) ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias : nullptr;
+    const float* rbp = (p.rowbias && !rb_uniform && m < p.m) ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = wn * TN * 16 + j * 16 + g * 4;
@@ -194,7 +210,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += b[r];
         }
-        if (rbp) {
+        if (rb_uniform) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rb_q[j][r];
+        } else if (rbp) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(rbp + n);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += b[r];
