@@ -203,3 +203,50 @@ def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libcontrolanimate_hip.so")
     with pytest.raises(_capi.CAHipUnavailable):
         _capi.lib()
+
+
+def test_non_square_latents_12_frames_two_controlnets_vs_oracle():
+    """BASELINE config 4 in miniature: non-square latents (16 x 24 -> token counts 384 / 96 / 24 / 6, none a
+    multiple of the 128-query / 64-key tiles), 12 frames (not a power of two), 81-token context (77 + 4 IP tokens,
+    stripped by the ControlNet processor), two ControlNets summed -- UNet eps against the fp32 oracle."""
+    from controlanimate_amd.configs import controlnet_config
+    from controlanimate_amd.controlnet import ControlNetModel
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from oracle.controlnet import ControlNetConfig, controlnet_forward, init_controlnet_weights
+    from oracle.unet3d import UNet3DConfig, init_unet3d_weights, unet3d_forward
+    ucfg = UNet3DConfig.v2(block_out_channels=SMALL)
+    uw = init_unet3d_weights(ucfg, seed=71)
+    unet = build_unet("v2", SMALL, uw, torch.float16)
+    ccfg = ControlNetConfig(block_out_channels=SMALL)
+    f, h, w = 12, 16, 24
+    g = torch.Generator().manual_seed(72)
+    sample = torch.randn(1, 4, f, h, w, generator=g)
+    ehs = torch.randn(1, 77, 768, generator=g) * 0.5
+    hints = [torch.rand(f, 3, 8 * h, 8 * w, generator=g) for _ in range(2)]
+    scales = [0.7, 1.1]
+    nets, cws = [], []
+    for i in range(2):
+        cw = init_controlnet_weights(ccfg, seed=73 + i)
+        net = ControlNetModel.from_config(controlnet_config(block_out_channels=SMALL))
+        net.load_state_dict(cw)
+        nets.append(net.to(DEV).prepare(DEV, torch.float16))
+        cws.append(cw)
+    # oracle: per-frame ControlNets on the (b f) batch, residuals summed, then the UNet
+    with torch.no_grad():
+        x2d = sample.permute(0, 2, 1, 3, 4).reshape(f, 4, h, w)
+        down_sum, mid_sum = None, None
+        for cw, hint, sc in zip(cws, hints, scales):
+            d, m = controlnet_forward(cw, ccfg, x2d, 300, ehs.expand(f, -1, -1), hint, conditioning_scale=sc, guess_mode=False)
+            down_sum = list(d) if down_sum is None else [a + b for a, b in zip(down_sum, d)]
+            mid_sum = m if mid_sum is None else mid_sum + m
+        to5 = lambda t: t.reshape(1, f, *t.shape[1:]).permute(0, 2, 1, 3, 4)
+        ref = unet3d_forward(uw, ucfg, sample, 300, ehs, down_block_additional_residuals=[to5(d) for d in down_sum],
+                             mid_block_additional_residual=to5(mid_sum))
+    cn = MultiControlNetResidualsPipeline(["a", "b"], scales, use_lcm=False, controlnets=nets, device=DEV)
+    cn.prep_control_images({"a": [x for x in hints[0]], "b": [x for x in hints[1]]}, do_classifier_free_guidance=False, guess_mode=False)
+    down, mid = cn(sample.to(DEV), 300, ehs.to(DEV), f, do_classifier_free_guidance=False, guess_mode=False)
+    out = unet(sample.to(DEV), 300, ehs.to(DEV), down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+    torch.cuda.synchronize()
+    r = rel(out, ref)
+    print("non-square 12-frame eps rel_l2 %.3e" % r)
+    assert out.shape == ref.shape and r < 1e-2, r
