@@ -34,18 +34,23 @@ struct GnParams {
   int act;
 };
 
-// Thread mapping: tx = lane over 16-byte channel chunks, ty = lane over rows; TX = 2^txlog is chosen
-// so that C/8 = TX * slots with slots <= 5 and (almost) no idle lanes: C = 320/640/1280 -> TX = 8/16/32
-// with 5 slots (a 64-wide mapping would idle 37% of the lanes at C = 320), otherwise TX = 64.  256/TX
-// rows are in flight per block iteration, every thread issuing all its slot loads back to back.
+// Thread mapping: tx = lane over 16-byte channel chunks, ty = lane over rows; TX = 2^txlog in {8,16,32,64} is the
+// choice with C/8 <= TX * slots (slots <= 5) that idles the fewest lanes, the smallest such TX on ties (more rows in
+// flight per block): C = 320/640/1280 -> TX = 8/16/32 with 5 slots, C = 128/256/512 (VAE) -> TX = 8/8/16 with
+// 2/4/4 slots (a 64-wide mapping idles 75% of the lanes at C = 128).  256/TX rows are in flight per block
+// iteration, every thread issuing all its slot loads back to back.
 __host__ __device__ inline int gn_txlog(int c8) {
-  if (c8 % 5 == 0) {
-    const int q = c8 / 5;
-    if (q == 8) return 3;
-    if (q == 16) return 4;
-    if (q == 32) return 5;
+  int best = 6, best_waste = 1 << 30;
+  for (int l = 3; l <= 6; ++l) {
+    const int tx = 1 << l, slots = (c8 + tx - 1) / tx;
+    if (slots > 5) continue;
+    const int waste = slots * tx - c8;
+    if (waste < best_waste) {
+      best_waste = waste;
+      best = l;
+    }
   }
-  return 6;
+  return best;
 }
 
 // grid: (nchunks, n_stat_groups)
