@@ -286,6 +286,7 @@ def main():
     rank, world, local_rank = WS.init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    local_rank %= torch.cuda.device_count()  # (ranks may share a GPU in a gloo rehearsal run, CA_DIST_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16

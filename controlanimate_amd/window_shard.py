@@ -28,11 +28,12 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # CA_DIST_BACKEND=gloo: several ranks sharing ONE GPU (rehearsal of the multi-rank flow on a 1-GPU box)
+            backend = os.environ.get("CA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
