@@ -68,6 +68,40 @@ def test_invalid_arguments_are_rejected_without_a_gpu(capi):
     assert lib.ca_groupnorm_partials_floats(32, 64, 1, 32) == 32 * 16 * 32 * 2  # small images: 4 rows per chunk
 
 
+def test_every_entry_point_rejects_bad_arguments_without_a_gpu(capi):
+    """The reference raises Python exceptions on malformed inputs; the C ABI returns a negative code and a
+    message naming the entry point, never crashes, never launches (all of this runs on the CPU-only builder)."""
+    lib = capi.lib()
+    fake = C.c_void_p(0x1000)  # never dereferenced on the host: validation fails first
+
+    def expect(rc, who):
+        assert rc < 0 and who.encode() in lib.ca_last_error(), (rc, lib.ca_last_error())
+
+    expect(lib.ca_gemm(None, None), "ca_gemm")
+    expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=12, lda=16, ldc=16, dtype=1)), None), "ca_gemm")        # K % 8
+    expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=16, lda=16, ldc=16, dtype=7)), None), "ca_gemm")        # dtype
+    expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=16, lda=16, ldc=16, dtype=1, ln_stats=fake)), None), "ca_gemm")  # ln pair
+    expect(lib.ca_conv3x3(None, None), "ca_conv3x3")
+    expect(lib.ca_conv3x3(C.byref(capi.ConvArgs(x=fake, w=fake, y=fake, images=1, hin=8, win=8, cin1=12, cout=16, stride=1, dtype=1)), None), "ca_conv3x3")  # Cin % 8
+    expect(lib.ca_conv3x3(C.byref(capi.ConvArgs(x=fake, w=fake, y=fake, images=1, hin=8, win=8, cin1=16, cout=16, stride=3, dtype=1)), None), "ca_conv3x3")  # stride
+    assert lib.ca_conv3x3_workspace_bytes(None) == 0
+    small = capi.ConvArgs(images=32, hin=8, win=8, cin1=1280, cout=1280, stride=1, dtype=1)
+    assert lib.ca_conv3x3_workspace_bytes(C.byref(small)) == 6 * 2048 * 1280 * 4        # 160 tiles -> 6 K ranges of fp32 slabs
+    big = capi.ConvArgs(images=32, hin=64, win=64, cin1=320, cout=320, stride=1, dtype=1)
+    assert lib.ca_conv3x3_workspace_bytes(C.byref(big)) == 0
+    expect(lib.ca_groupnorm_stats(C.byref(capi.GroupNormArgs(x=fake, partials=fake, images=2, hw=16, c1=30, groups=32, frames_per_stat=1, dtype=1)), None),
+           "ca_groupnorm_stats")                                                                               # C % 8
+    expect(lib.ca_groupnorm_apply(C.byref(capi.GroupNormArgs(x=fake, partials=fake, images=3, hw=16, c1=64, groups=32, frames_per_stat=2, dtype=1)), None),
+           "ca_groupnorm_apply")                                                                               # frames_per_stat
+    expect(lib.ca_layernorm(C.byref(capi.LayerNormArgs(x=fake, rows=4, c=320, dtype=1)), None), "ca_layernorm")                          # no y / stats
+    expect(lib.ca_layernorm(C.byref(capi.LayerNormArgs(x=fake, stats=fake, pos=fake, rows=4, c=320, rows_per_frame=1, frames=1, dtype=1)), None), "ca_layernorm")
+    expect(lib.ca_attention(C.byref(capi.AttnArgs(q=fake, k=fake, v=fake, o=fake, head_dim=20, batches=1, heads=1, nq=4, nk=4, inner_count=1,
+                                                 kv_inner_count=1, kv_div=1, dtype=1)), None), "ca_attention")      # head_dim % 8
+    expect(lib.ca_attention(C.byref(capi.AttnArgs(q=fake, k=fake, v=fake, o=fake, head_dim=40, batches=1, heads=1, nq=4, nk=8, inner_count=1,
+                                                 kv_inner_count=1, kv_div=1, q_row=40, k_row=40, o_row=40, dtype=1, causal=1)), None), "ca_attention")  # causal nq != nk
+    expect(lib.ca_softmax_rows(fake, fake, 4, 10, 12, 12, 1.0, 1, None), "ca_softmax_rows")                       # cols % 4
+
+
 def test_no_cpu_fallback_when_library_missing(monkeypatch):
     from controlanimate_amd import _capi
     monkeypatch.setattr(_capi, "_lib", None)
