@@ -53,7 +53,48 @@ def parse():
                          "(tests/test_graph_gpu.py), ~1 ms instead of ~50 ms of host time per step, so the loop stays "
                          "GPU-bound when N ranks share one host; falls back to eager if the capture fails")
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)  # (old spelling of the default)
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="multi-rank plumbing rehearsal WITHOUT the hot path (runs on a CPU box over gloo): rendezvous, "
+                         "weight-arena broadcast, barriers, max-over-ranks timing, rank-0 JSON with `dry_run: true` and "
+                         "`value: null`.  Never a measurement; used by tests/test_bench_launch.py")
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: this process becomes a GPU-free parent
+    that starts N fresh rank processes (one per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, 127.0.0.1 rendezvous), relays rank 0's JSON line and returns non-zero if any rank fails.
+    Nothing here touches HIP: a process that has initialised the GPU must never be re-executed, and
+    children are started with subprocess (fresh interpreters), not fork."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+        try:
+            pr.wait(timeout=120 if rc == 0 else 5)
+        except subprocess.TimeoutExpired:
+            pr.kill()  # exact PID of a child this parent started
+            pr.wait()
+        rc = rc or pr.returncode
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    return rc
 
 
 def randomize_zero_init_(model, std=0.02, seed=0):
@@ -275,8 +316,50 @@ def time_vae(args, device, dtype):
     return out
 
 
+def plumbing_only(args):
+    """The multi-rank flow of main() with the hot path replaced by a sleep: what a CPU box can rehearse."""
+    from controlanimate_amd import window_shard as WS
+    rank, world, _ = WS.init_distributed()
+    g = torch.Generator().manual_seed(11)
+    arenas = [torch.randint(0, 255, (1 << 20,), dtype=torch.uint8, generator=g) if rank == 0 else torch.zeros(1 << 20, dtype=torch.uint8)
+              for _ in range(1 + args.controlnets)]
+    ref = int(arenas[0][:4096].to(torch.int64).sum()) if rank == 0 else None
+    bytes_bcast = WS.broadcast_weights(arenas)
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    chk = torch.tensor([int(arenas[0][:4096].to(torch.int64).sum())], dtype=torch.int64)
+    if world > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+        lo = chk.clone()
+        torch.distributed.all_reduce(chk, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        assert int(chk) == int(lo), "ranks disagree on the broadcast arena"
+    if rank == 0:
+        assert ref == int(chk)
+        print(json.dumps({"metric": "frames_per_sec", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "dry_run": True, "scaling": "weak",
+                          "config": {"workload": "plumbing rehearsal (no hot path)", "weight_broadcast_bytes": bytes_bcast,
+                                     "parallelism": f"window-shard x{world}" if world > 1 else "single GPU"},
+                          "max_rank_elapsed_s": float(elapsed)}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}; they must agree")
+    if args.plumbing_only:
+        return plumbing_only(args)
     from controlanimate_amd import kernels as K
     from controlanimate_amd import window_shard as WS
     from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
