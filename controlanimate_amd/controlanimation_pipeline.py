@@ -19,6 +19,7 @@ sampler draws its per-step noise from the GLOBAL CPU RNG (:1601), diffusers' LCM
 """
 from __future__ import annotations
 
+import logging
 import time
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional, Sequence, Union
@@ -29,6 +30,8 @@ import torch
 from . import kernels as K
 from .controlresiduals_pipeline import MultiControlNetResidualsPipeline, _image_to_chw01
 from .schedulers import DiffusersLCMScheduler, LCMScheduler, get_w_embedding
+
+logger = logging.getLogger(__name__)
 
 
 @dataclass
@@ -230,6 +233,7 @@ class ControlAnimationPipeline:
         self.last_step_times = []
         use_graph = bool(self.use_hip_graph) and device.type == "cuda" and len(timesteps) > 1
         self.graph_replays = 0
+        self.graph_fallback_reason = None
         x_static = t_static = graph = eps_static = None
         if use_graph:
             hh, ww = latents.shape[3], latents.shape[4]
@@ -259,8 +263,10 @@ class ControlAnimationPipeline:
                         with torch.cuda.graph(g_):
                             eps_static = model_eps(x_static, t_static)
                         graph = g_
-                    except Exception:  # capture is an optimisation only
+                    except Exception as exc:  # capture is an optimisation only -- but never a silent one
                         use_graph, graph = False, None
+                        self.graph_fallback_reason = f"{type(exc).__name__}: {exc}"
+                        logger.warning("hipGraph capture failed (%s); this window runs eagerly", self.graph_fallback_reason)
                         torch.cuda.synchronize()
                 if graph is not None:
                     graph.replay()

@@ -756,10 +756,18 @@ inline unsigned desc_bytes(int64_t elems) {
 }
 
 int check_epilogue(const char* who, int n, int geglu, int out_f32, int64_t ldc, int64_t ld_res, const void* res) {
-  CA_REQUIRE(n > 0 && n % 4 == 0, "%s: N=%d must be a positive multiple of 4", who, n);
+  // N = 4 (conv_out) takes the direct 4-column epilogue; everything wider goes through the LDS-staged
+  // epilogue, which moves 8-column (16-byte) chunks: N, ldc and ld_res must then be multiples of 8
+  // (N = 12, 20, ... would store 8 values at column N-4: past the row end)
+  CA_REQUIRE(n == 4 || (n >= 8 && n % 8 == 0), "%s: N=%d must be 4 or a multiple of 8", who, n);
   CA_REQUIRE(!geglu || n % 8 == 0, "%s: geglu needs N %% 8 == 0", who);
-  CA_REQUIRE(ldc % (geglu ? 2 : 4) == 0, "%s: ldc=%lld misaligned", who, (long long)ldc);
-  CA_REQUIRE(!res || ld_res % 4 == 0, "%s: ld_res=%lld misaligned", who, (long long)ld_res);
+  if (n >= 8) {
+    CA_REQUIRE(ldc % (geglu ? 4 : 8) == 0, "%s: ldc=%lld must be a multiple of %d", who, (long long)ldc, geglu ? 4 : 8);
+    CA_REQUIRE(!res || ld_res % 8 == 0, "%s: ld_res=%lld must be a multiple of 8", who, (long long)ld_res);
+  } else {
+    CA_REQUIRE(ldc % 4 == 0, "%s: ldc=%lld misaligned", who, (long long)ldc);
+    CA_REQUIRE(!res || ld_res % 4 == 0, "%s: ld_res=%lld misaligned", who, (long long)ld_res);
+  }
   (void)out_f32;
   return CA_OK;
 }

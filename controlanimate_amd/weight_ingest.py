@@ -18,10 +18,14 @@ Fusing happens on the fp32 master parameters; call `model.prepare()` afterwards 
 """
 from __future__ import annotations
 
+import logging
+import os
 import re
 from typing import Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
 
 import torch
+
+logger = logging.getLogger(__name__)
 
 UNET_PREFIX = "model.diffusion_model."
 VAE_PREFIX = "first_stage_model."
@@ -221,6 +225,43 @@ def fuse_lora(unet: torch.nn.Module, state_dict: Mapping[str, torch.Tensor], lor
     return fused
 
 
+def lora_text_encoder_keys(state_dict: Mapping[str, torch.Tensor]) -> List[str]:
+    """Keys of a LoRA file that target the CLIP text encoder (kohya `lora_te_*`, diffusers `text_encoder.*`)."""
+    return [k for k in state_dict if k.startswith("lora_te_") or k.startswith("text_encoder.")]
+
+
+def fuse_lora_text_encoder(text_encoder: torch.nn.Module, state_dict: Mapping[str, torch.Tensor], lora_scale: float = 1.0,
+                           use_network_alpha: bool = True) -> List[str]:
+    """Text-encoder half of diffusers' load_lora_weights + fuse_lora (what util.py:155-156 runs): kohya keys
+    `lora_te_text_model_encoder_layers_<i>_{self_attn_{q,k,v,out}_proj,mlp_fc{1,2}}.lora_{down,up}.weight` (+ `.alpha`)
+    and diffusers keys `text_encoder.<path>.lora_linear_layer.{down,up}.weight` are added to the master weights
+    with the same scale * alpha / rank rule as the UNet half."""
+    fused = fuse_lora(text_encoder, {k: v for k, v in state_dict.items() if k.startswith("lora_te_")}, lora_scale,
+                      use_network_alpha, prefix="lora_te")
+    for key, down in state_dict.items():
+        if not (key.startswith("text_encoder.") and key.endswith("down.weight")):
+            continue
+        stem = key[: -len("down.weight")]
+        up = state_dict[stem + "up.weight"]
+        path = key[len("text_encoder."):]
+        path = re.sub(r"\.(lora_linear_layer|lora)\.down\.weight$", "", path)
+        path = re.sub(r"\.(to_q|to_k|to_v|to_out)_lora\.down\.weight$", lambda m: "." + {"to_q": "q_proj", "to_k": "k_proj", "to_v": "v_proj", "to_out": "out_proj"}[m.group(1)], path)
+        scale = lora_scale
+        alpha_key = stem[:-1] + ".alpha" if stem.endswith(".") else stem + "alpha"
+        if use_network_alpha and alpha_key in state_dict:
+            scale *= float(state_dict[alpha_key]) / down.shape[0]
+        _add_delta(_module_weight(text_encoder, path), up, down, scale)
+        fused.append(path)
+    return fused
+
+
+def convert_ldm_clip_checkpoint(checkpoint: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """convert_from_ckpt.py:716-728: the CLIP text tower of an LDM checkpoint is its `cond_stage_model.transformer.`
+    sub-dict under transformers' own key names (returned as a state dict; the reference instantiates the model)."""
+    pre = "cond_stage_model.transformer."
+    return {k[len(pre):]: v for k, v in checkpoint.items() if k.startswith(pre)}
+
+
 def convert_lora(unet: torch.nn.Module, state_dict: Mapping[str, torch.Tensor], alpha: float = 0.6) -> List[str]:
     """The reference's own kohya fuse (convert_lora_safetensor_to_diffusers.py:51-115): `.alpha` entries ignored."""
     return fuse_lora(unet, state_dict, lora_scale=alpha, use_network_alpha=False)
@@ -244,8 +285,11 @@ def fuse_motion_lora(unet: torch.nn.Module, state_dict: Mapping[str, torch.Tenso
 
 
 # ------------------------------------------------------------------------------------ files and orchestration
-def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
-    """.safetensors or torch pickle (.ckpt/.pth/.bin); unwraps a top-level "state_dict"."""
+def read_checkpoint(path: str, allow_pickle: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+    """.safetensors or torch pickle (.ckpt/.pth/.bin); unwraps a top-level "state_dict".
+    Pickles are read with `weights_only=True` (tensors and plain containers only).  Community .ckpt files that
+    carry arbitrary Python objects need the explicit opt-in `allow_pickle=True` (or CA_ALLOW_PICKLE=1): that
+    executes code from the file, exactly as the reference's bare `torch.load` does (util.py:117,127)."""
     if path.endswith(".safetensors"):
         from safetensors import safe_open
         out = {}
@@ -253,7 +297,15 @@ def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
             for k in f.keys():
                 out[k] = f.get_tensor(k)
         return out
-    sd = torch.load(path, map_location="cpu", weights_only=False)
+    if allow_pickle is None:
+        allow_pickle = os.environ.get("CA_ALLOW_PICKLE", "0") == "1"
+    try:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as exc:
+        if not allow_pickle:
+            raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(exc).__name__}); pass allow_pickle=True "
+                               f"(or CA_ALLOW_PICKLE=1) only for files you trust") from exc
+        sd = torch.load(path, map_location="cpu", weights_only=False)
     return sd["state_dict"] if isinstance(sd, dict) and "state_dict" in sd else sd
 
 
@@ -268,8 +320,9 @@ def load_motion_module(unet: torch.nn.Module, state_dict: Mapping[str, torch.Ten
 
 def load_weights(animation_pipeline, motion_module_path: str = "", motion_module_lora_configs: Iterable[dict] = (),
                  dreambooth_model_path: str = "", lora_model_path: Sequence[str] = (), lora_alpha: Sequence[float] = ()):
-    """Same arguments and order of operations as the reference's load_weights (util.py:101-175).  The text
-    encoder conversion (convert_ldm_clip_checkpoint) is not performed: CLIP stays the caller's."""
+    """Same arguments and order of operations as the reference's load_weights (util.py:101-175), including
+    the text-encoder halves (dreambooth CLIP tower, `lora_te_*` deltas) when the pipeline carries a fusable text_encoder;
+    when it does not, the skipped tensors are logged (never silently dropped)."""
     unet = animation_pipeline.unet
     if motion_module_path:
         load_motion_module(unet, read_checkpoint(motion_module_path))
@@ -279,15 +332,32 @@ def load_weights(animation_pipeline, motion_module_path: str = "", motion_module
         if vae is not None and hasattr(vae, "load_state_dict"):
             vae.load_state_dict(convert_ldm_vae_checkpoint(sd, vae.config))
         unet.load_state_dict(convert_ldm_unet_checkpoint(sd, unet.config), strict=False)
+        te = getattr(animation_pipeline, "text_encoder", None)
+        te_sd = convert_ldm_clip_checkpoint(sd)
+        if te_sd:
+            if te is not None and hasattr(te, "load_state_dict"):
+                te.load_state_dict(te_sd, strict=False)
+            else:
+                logger.warning("dreambooth checkpoint carries %d text-encoder tensors but the pipeline has no text_encoder "
+                               "to load them into: prompts will be embedded by the base CLIP weights", len(te_sd))
     if isinstance(lora_model_path, str):
         lora_model_path = [lora_model_path] if lora_model_path else []
     if isinstance(lora_alpha, (int, float)):
         lora_alpha = [lora_alpha] * len(lora_model_path)
     for path, alpha in zip(lora_model_path, lora_alpha):
-        fuse_lora(unet, read_checkpoint(path), lora_scale=float(alpha))
+        lsd = read_checkpoint(path)
+        fuse_lora(unet, lsd, lora_scale=float(alpha))
+        # the reference's load_lora_weights + fuse_lora (util.py:155-156) also fuses the text-encoder half
+        te = getattr(animation_pipeline, "text_encoder", None)
+        te_keys = lora_text_encoder_keys(lsd)
+        if te_keys and te is not None and isinstance(te, torch.nn.Module):
+            fuse_lora_text_encoder(te, lsd, lora_scale=float(alpha))
+        elif te_keys:
+            logger.warning("%s: %d text-encoder LoRA tensors skipped (no fusable text_encoder attached); prompt embeddings "
+                           "will differ from the reference for this LoRA", path, len(te_keys))
     for cfg in motion_module_lora_configs:
         fuse_motion_lora(unet, read_checkpoint(cfg["path"]), float(cfg["alpha"]))
-    for m in (unet, getattr(animation_pipeline, "vae", None)):
+    for m in (unet, getattr(animation_pipeline, "vae", None), getattr(animation_pipeline, "text_encoder", None)):
         if m is not None and getattr(m, "arena", None) is not None:
             m.prepare()  # repack the device arena from the updated master weights
     return animation_pipeline

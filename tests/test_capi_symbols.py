@@ -81,6 +81,11 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu(capi):
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=12, lda=16, ldc=16, dtype=1)), None), "ca_gemm")        # K % 8
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=16, lda=16, ldc=16, dtype=7)), None), "ca_gemm")        # dtype
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=16, lda=16, ldc=16, dtype=1, ln_stats=fake)), None), "ca_gemm")  # ln pair
+    # N = 12 / ldc = 12 pass a "multiple of 4" check but the LDS-staged epilogue stores 16-byte chunks
+    expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=12, k1=16, lda=16, ldc=16, dtype=1)), None), "ca_gemm")
+    expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=16, lda=16, ldc=12, dtype=1)), None), "ca_gemm")
+    expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, residual=fake, m=16, n=16, k1=16, lda=16, ldc=16, ld_res=12, dtype=1)), None), "ca_gemm")
+    expect(lib.ca_conv3x3(C.byref(capi.ConvArgs(x=fake, w=fake, y=fake, images=1, hin=8, win=8, cin1=16, cout=12, stride=1, dtype=1)), None), "ca_conv3x3")
     expect(lib.ca_conv3x3(None, None), "ca_conv3x3")
     expect(lib.ca_conv3x3(C.byref(capi.ConvArgs(x=fake, w=fake, y=fake, images=1, hin=8, win=8, cin1=12, cout=16, stride=1, dtype=1)), None), "ca_conv3x3")  # Cin % 8
     expect(lib.ca_conv3x3(C.byref(capi.ConvArgs(x=fake, w=fake, y=fake, images=1, hin=8, win=8, cin1=16, cout=16, stride=3, dtype=1)), None), "ca_conv3x3")  # stride
