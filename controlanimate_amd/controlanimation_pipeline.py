@@ -53,6 +53,8 @@ class ControlAnimationPipeline:
         self.ip_adapter = None
         self.device = torch.device("cuda")
         self.last_step_times: List[float] = []
+        self.record_eps = False      # True: keep every step's raw UNet eps ([rep,4,f,h,w] fp32, CPU) in `eps_history` (parity tests)
+        self.eps_history: List[torch.Tensor] = []
 
     def to(self, device):
         self.device = torch.device(device)
@@ -231,6 +233,7 @@ class ControlAnimationPipeline:
         cn_prompt = lcm_prompt_embeds if cn_single else cfg_prompt_embeds
         denoised = None
         self.last_step_times = []
+        self.eps_history = []
         use_graph = bool(self.use_hip_graph) and device.type == "cuda" and len(timesteps) > 1
         self.graph_replays = 0
         self.graph_fallback_reason = None
@@ -277,6 +280,8 @@ class ControlAnimationPipeline:
             else:
                 x = K.latents_to_nhwc(latents, cpad, rep, in_scale, unet.act_dtype)          # [(rep f), h, w, 8]
                 eps = model_eps(x, t)
+            if self.record_eps:
+                self.eps_history.append(K.nhwc_to_ncfhw_f32(eps, rep, 4, f).cpu())
             coef, clip = sched.coefficients(idx)
             noise = None
             if sched.needs_noise and len(sched.timesteps) > 1:

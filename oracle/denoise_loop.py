@@ -86,6 +86,7 @@ def denoise_loop(unet_sd, unet_cfg: UNet3DConfig, inp: LoopInputs, controlnets: 
         if do_cfg and not inp.guess_mode and not inp.use_lcm:
             prep = [torch.cat([p] * 2) for p in prep]  # controlresiduals_pipeline.py:268-269
     eps_hist: List[torch.Tensor] = []
+    raw_hist: List[torch.Tensor] = []   # the UNet's raw output (both CFG halves)
     lat_hist: List[torch.Tensor] = []
     denoised = None
     for i, t in enumerate(timesteps):
@@ -95,17 +96,22 @@ def denoise_loop(unet_sd, unet_cfg: UNet3DConfig, inp: LoopInputs, controlnets: 
         down = mid = None
         if controlnets:
             single = inp.use_lcm or inp.guess_mode or not do_cfg
+            # the reference casts the ControlNet's latent input and prompt to fp16 (controlresiduals_pipeline.py:295-297)
+            cn_in = (lcm_in if single else model_in).half().float()
+            cn_prompt = (lcm_prompt if single else prompt).half().float()
             down, mid = multi_controlnet_residuals(
-                controlnets, cn_cfg, lcm_in if single else model_in, t, lcm_prompt if single else prompt,
+                controlnets, cn_cfg, cn_in, t, cn_prompt,
                 frame_count=f, prep_images=prep, cond_scale=inp.cond_scale, guess_mode=inp.guess_mode,
                 strip_tokens=4 if inp.use_ip else 0)
         noise = inp.step_noises[i] if inp.step_noises is not None else None
         if inp.use_lcm:
             pred = unet3d_forward(unet_sd, unet_cfg, lcm_in, t, lcm_prompt, down, mid, timestep_cond=w_emb, ip=ip)
+            raw_hist.append(pred)
             eps_hist.append(pred)
             latents, denoised = sched.step(pred, i, t, latents, noise=noise)
         else:
             pred = unet3d_forward(unet_sd, unet_cfg, model_in, t, prompt, down, mid, ip=ip)
+            raw_hist.append(pred)
             if do_cfg:
                 pu, pc = pred.chunk(2)
                 pred = pu + inp.guidance_scale * (pc - pu)
@@ -116,4 +122,4 @@ def denoise_loop(unet_sd, unet_cfg: UNet3DConfig, inp: LoopInputs, controlnets: 
                 latents, _ = sched.step(pred, t, latents)
         lat_hist.append(latents)
     final = denoised if inp.use_lcm else latents  # pipeline decodes `denoised` for native LCM (:859-863)
-    return {"timesteps": timesteps, "eps": eps_hist, "latents": lat_hist, "final": final}
+    return {"timesteps": timesteps, "eps": eps_hist, "eps_raw": raw_hist, "latents": lat_hist, "final": final}

@@ -1,0 +1,87 @@
+"""GPU: the HIP pipeline (`ControlAnimationPipeline.__call__`: prepare_latents, ControlNet stack, UNet3D, fused CFG +
+sampler kernel) replays the scenarios captured from the REFERENCE's own `__call__` (tests/golden/loop_reference.npz,
+make_loop_golden.py) -- same frames, prompts, seeds, stand-in VAE -- and is compared step by step.
+
+Bounds.  eps = the UNet's raw output of a step (both CFG halves).  Step 0 sees the reference's exact inputs: north-star
+bound 1e-2 (measured ~2e-3).  Later steps also carry the trajectory error: the CFG combine multiplies the independent
+fp16 rounding errors of the two halves by sqrt(g^2 + (g-1)^2) (~10 at g = 7.5, ~1.6 at g = 1.5) per step, so their bound
+is stated per scenario and the x0-prediction of the LCM samplers (what the pipeline decodes) is checked as well."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from loop_stubs import PX, SCENARIOS, SMALL, StubVAE, scenario_inputs  # noqa: E402
+
+FX = np.load(os.path.join(HERE, "golden", "loop_reference.npz"))
+DEV = "cuda:0"
+
+
+def fx(name, key):
+    return torch.from_numpy(np.asarray(FX[f"{name}/{key}"]))
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+# scenario -> (eps bound of steps > 0, bound on the latents after the last step)
+BOUNDS = {"custom_lcm": (1e-2, 1e-2), "ddim_cfg": (6e-2, 1.5e-1), "lcm_lora_guess_overlap": (1.5e-2, 1.5e-2), "overlap_no_img2img": (6e-2, 1e-1)}
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_hip_pipeline_replays_the_reference_call(name):
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS, controlnet_config, unet_config
+    from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
+    from controlanimate_amd.controlnet import ControlNetModel
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.schedulers import get_scheduler
+    from controlanimate_amd.unet import UNet3DConditionModel
+    from oracle.controlnet import ControlNetConfig, init_controlnet_weights
+    from oracle.unet3d import UNet3DConfig, init_unet3d_weights
+    sc = SCENARIOS[name]
+    frames, last, pos, neg = scenario_inputs(name)
+    over = {"time_cond_proj_dim": 256} if sc["unet"] == "lcm" else {}
+    uw = init_unet3d_weights(UNet3DConfig.v2(block_out_channels=SMALL, **over), seed=int(FX[f"{name}/unet_weight_seed"]))
+    unet = UNet3DConditionModel.from_config(unet_config("v2", block_out_channels=SMALL, **over))
+    unet.load_state_dict(uw)
+    unet.to(DEV)
+    nets = []
+    for i in range(sc["nets"]):
+        net = ControlNetModel.from_config(controlnet_config(block_out_channels=SMALL))
+        net.load_state_dict(init_controlnet_weights(ControlNetConfig(block_out_channels=SMALL), seed=60 + i))
+        nets.append(net.to(DEV))
+    sched = None if sc["scheduler"] is None else get_scheduler(sc["scheduler"], **NOISE_SCHEDULER_KWARGS)
+    pipe = ControlAnimationPipeline(vae=StubVAE(), text_encoder=None, tokenizer=None, unet=unet, scheduler=sched).to(DEV)
+    pipe.record_eps = True
+    cn = MultiControlNetResidualsPipeline([f"synthetic-{i}" for i in range(len(nets))], sc["cond_scale"], use_lcm=sc["use_lcm"],
+                                          controlnets=nets, device=DEV) if nets else None
+    lat_steps = []
+    torch.manual_seed(sc["seed"])
+    gen = torch.Generator().manual_seed(sc["seed"])
+    out = pipe(video_length=sc["frames"], input_frames=frames, height=PX, width=PX, num_inference_steps=sc["steps"], strength=sc["strength"],
+               guidance_scale=sc["guidance"], generator=gen, overlaps=sc["overlaps"], multicontrolnetresiduals_pipeline=cn,
+               prompt_embeds=pos, negative_prompt_embeds=neg, last_output_frames=last if last else None, use_lcm=sc["use_lcm"],
+               guess_mode=sc["guess_mode"], use_img2img=sc["use_img2img"], output_type="latent",
+               callback=lambda i, t, l: lat_steps.append(l.clone())).videos
+    torch.cuda.synchronize()
+    n = int(FX[f"{name}/n_steps"])
+    assert len(pipe.eps_history) == n == len(lat_steps)
+    e_later, l_final = BOUNDS[name]
+    errs = []
+    for i in range(n):
+        ref = fx(name, f"eps{i}")
+        assert tuple(pipe.eps_history[i].shape) == tuple(ref.shape)
+        errs.append(rel(pipe.eps_history[i], ref))
+    lerrs = [rel(lat_steps[i], fx(name, f"latents{i}")) for i in range(n)]
+    print(name, "eps rel_l2 per step:", ["%.2e" % e for e in errs], "latents:", ["%.2e" % e for e in lerrs])
+    assert errs[0] < 1e-2, errs          # identical inputs: the north-star bound
+    assert max(errs) < e_later, errs
+    assert lerrs[-1] < l_final, lerrs
+    assert rel(out, fx(name, "final")) < l_final   # (native LCM: the x0 prediction `denoised`, which is what gets decoded)

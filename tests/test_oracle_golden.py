@@ -168,3 +168,29 @@ def test_checkpoint_key_contract_full_width():
     for version, cfg in (("v1", UNet3DConfig.v1()), ("v2", UNet3DConfig.v2())):
         mine = {k: list(v) for k, v in unet3d_param_shapes(cfg, include_dead=True).items()}
         assert mine == ref[version]["keys"], version
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ControlNet body: pinned by the reference's OWN blocks (tests/golden/make_controlnet_golden.py assembles an SD1.5
+# ControlNet from animatediff/models/unet_blocks.py with use_motion_module=False, one frame per image).
+@pytest.mark.parametrize("tag,boc", [("w64", SMALL), ("full", (320, 640, 1280, 1280))])
+def test_controlnet_oracle_matches_reference_blocks(tag, boc):
+    from oracle.controlnet import ControlNetConfig, controlnet_forward, init_controlnet_weights
+    fx = load("controlnet_refblocks.npz")
+    cfg = ControlNetConfig(block_out_channels=boc)
+    w = init_controlnet_weights(cfg, seed=int(fx[f"{tag}_seed"]))
+    check_weights(w, fx, f"{tag}_checksum")
+    x, ehs, cond = T(fx[f"{tag}_sample"]), T(fx[f"{tag}_ehs"]), T(fx[f"{tag}_cond"])
+    kept = range(12) if tag == "w64" else (0, 5, 11)
+    for mode, guess in (("plain", False), ("guess", True)):
+        down, mid = controlnet_forward(w, cfg, x, int(fx[f"{tag}_{mode}_t"]), ehs, cond, float(fx[f"{tag}_{mode}_scale"]), guess)
+        assert len(down) == 12
+        for i in kept:
+            assert_close(down[i], T(fx[f"{tag}_{mode}_down{i}"]), 3e-5)
+        assert_close(mid, T(fx[f"{tag}_{mode}_mid"]), 3e-5)
+    if tag == "w64":  # CNAttnProcessor2_0 installed by the IP-Adapter path: the 4 image tokens are dropped
+        ehs81 = torch.cat([ehs, T(fx["w64_cn_ip_tokens"])], dim=1)
+        down, mid = controlnet_forward(w, cfg, x, 500, ehs81, cond, 0.5, False, strip_tokens=4)
+        for i in range(12):
+            assert_close(down[i], T(fx[f"w64_cn_down{i}"]), 3e-5)
+        assert_close(mid, T(fx["w64_cn_mid"]), 3e-5)
