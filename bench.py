@@ -29,8 +29,27 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STEPS_PER_WINDOW = 20
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
+
+# BASELINE.json configs.  tflop = algorithmic work per denoise step (2*MAC of conv, linear,
+# QK^T, PV): UNet3D + n_controlnets x ControlNet at the batch the reference feeds it (guess mode / native LCM: b = 1).
+CONFIGS = {
+    1: dict(name="config 1: SD1.5 + mm_sd_v15 (v1), 8 frames 256x256, 4 DDIM steps, CFG 7.5, no ControlNet", version="v1", frames=8,
+            height=256, width=256, steps=4, scheduler="DDIMScheduler", guidance=7.5, controlnets=0, guess_mode=False, ip=False, overlap=0,
+            unet_tflop=4.09, cn_tflop=0.0),
+    2: dict(name="config 2: SD1.5 + mm_sd_v15_v2, 16 frames 512x512, 20 LCM steps, CFG g=1.1 (batch 2), 1 ControlNet", version="v2", frames=16,
+            height=512, width=512, steps=20, scheduler="LCMScheduler", guidance=1.1, controlnets=1, guess_mode=False, ip=False, overlap=0,
+            unet_tflop=35.53, cn_tflop=9.07),
+    3: dict(name="config 3: SampleConfig.yaml-equivalent, 4 ControlNets + 8-frame latent overlap, 16 frames 512x512, Euler 30 steps, CFG 7.5",
+            version="v2", frames=16, height=512, width=512, steps=30, scheduler="EulerDiscreteScheduler", guidance=7.5, controlnets=4,
+            guess_mode=False, ip=False, overlap=8, unet_tflop=35.53, cn_tflop=9.07),
+    4: dict(name="config 4: IP-Adapter (81 tokens) + LCM-LoRA + 2 ControlNets (guess mode), 16 frames 512x768, 20 LCM steps, CFG g=1.35",
+            version="v2", frames=16, height=512, width=768, steps=20, scheduler="LCMScheduler", guidance=1.35, controlnets=2, guess_mode=True,
+            ip=True, overlap=0, unet_tflop=56.20, cn_tflop=7.38),
+    5: dict(name="config 5: mm_sd_v15_v2, 32 frames 768x768 with 4-frame overlap blending, 20 LCM steps, CFG g=1.1, no ControlNet",
+            version="v2", frames=32, height=768, width=768, steps=20, scheduler="LCMScheduler", guidance=1.1, controlnets=0, guess_mode=False,
+            ip=False, overlap=4, unet_tflop=181.91, cn_tflop=0.0),
+}
 
 
 def parse():
@@ -38,11 +57,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=16)
-    ap.add_argument("--size", type=int, default=512, help="frame height = width in pixels")
-    ap.add_argument("--controlnets", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = the headline workload)")
+    ap.add_argument("--frames", type=int, default=None, help="override the config's frames per window")
+    ap.add_argument("--size", type=int, default=None, help="override: frame height = width in pixels")
+    ap.add_argument("--controlnets", type=int, default=None, help="override the config's number of ControlNets")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-config2", action="store_true",
+                    help="also time ONE full config-2 denoise step (44.6 TFLOP: ControlNet + UNet3D, fp32 oracle) on the host cores: "
+                         "about a minute of CPU work and ~40 GB of host memory; off by default so the run stays within minutes")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="also print the per-shape GEMM/conv table (stderr)")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing (reported beside the metric)")
@@ -116,6 +139,10 @@ def tile_name(m: int, n: int, k: int, conv: bool) -> str:
         return "reg_128x128" if wide else "reg_128x64"
     if conv and n % 128 == 0 and cdiv(m, 128) * (n // 128) < 384 and k // 64 >= 48:
         return "128x128_splitk"
+    if n % 320 == 0 and k // 64 >= 10:  # ping-pong 128x320 kernel where the 128x128 grid under-fills the chip (ca_gemm.hip)
+        tiles = cdiv(m, 128) * (n // 320)
+        if 128 <= tiles <= 256 or (tiles <= 512 and not conv and k // 64 >= 20):
+            return "pp128x320"
     if (not conv) and n >= 5120 and k >= 640 and n % 128 == 0 and cdiv(m, 256) * (n // 128) >= 512:
         return "256x128"
     wide = n % 128 == 0 and cdiv(m, 128) * cdiv(n, 128) >= 512
@@ -130,24 +157,38 @@ def rocprof_kernel_name(family: str, dtype: str) -> str:
     if tile.startswith("reg_"):
         return ""
     dt = 1 if dtype == "fp16" else 0
+    if tile == "pp128x320":
+        return f"k_gemm_pp2<{dt}, {1 if op == 'conv3x3' else 0}"
     bm, bn = tile.replace("_splitk", "").split("x")
     waves = "4, 2" if tile == "256x128" else ("4, 1" if tile == "128x64" else "2, 2")
     return f"k_gemm_dma<{dt}, {bm}, {bn}, {waves}, {1 if op == 'conv3x3' else 0}, "
 
 
-def pmc_traffic(kernel_prefix: str):
-    """HBM-side bytes per launch of a kernel from the committed PMC summary (profiles/round1_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when the summary has no entry."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-    if not kernel_prefix or not os.path.exists(path):
-        return None
-    with open(path) as fh:
-        table = json.load(fh)["kernels"]
-    for name, row in table.items():
-        if name.startswith(kernel_prefix):
-            return row["hbm_bytes_per_launch"]
-    return None
+PMC_SUMMARIES = ("round2_pmc_traffic.json", "round1_pmc_traffic.json")
+
+
+def pmc_traffic(kernel_prefix: str, workload_key: str, dtype: str):
+    """HBM-side bytes per launch of a kernel from a committed PMC summary (profiles/roundN_pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py`, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950).  Counters cannot be collected by this process itself, so the figure is attached ONLY when the summary
+    was captured on the same workload and dtype (the summary records both); otherwise (None, None).
+    Returns (bytes_per_launch, source file)."""
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    if not kernel_prefix:
+        return None, None
+    for fn in PMC_SUMMARIES:
+        path = os.path.join(base, fn)
+        if not os.path.exists(path):
+            continue
+        with open(path) as fh:
+            doc = json.load(fh)
+        meta = doc.get("workload", {"key": "config2", "dtype": "fp16"})  # (round 1 summary: config 2, fp16)
+        if meta.get("key") != workload_key or meta.get("dtype") != dtype:
+            continue
+        for name, row in doc["kernels"].items():
+            if name.startswith(kernel_prefix):
+                return row["hbm_bytes_per_launch"], fn
+    return None, None
 
 
 class KernelTimer:
@@ -243,17 +284,29 @@ class KernelTimer:
         return agg
 
 
-def build_models(args, device, dtype):
+def build_models(wl, device, dtype):
     from controlanimate_amd.configs import controlnet_config, unet_config
     from controlanimate_amd.controlnet import ControlNetModel
     from controlanimate_amd.unet import UNet3DConditionModel
     torch.manual_seed(0)
     with torch.device(device):
-        unet = UNet3DConditionModel.from_config(unet_config("v2"))
-        nets = [ControlNetModel.from_config(controlnet_config()) for _ in range(args.controlnets)]
+        unet = UNet3DConditionModel.from_config(unet_config(wl["version"]))
+        nets = [ControlNetModel.from_config(controlnet_config()) for _ in range(wl["controlnets"])]
     randomize_zero_init_(unet, seed=1)
     for i, n in enumerate(nets):
         randomize_zero_init_(n, seed=2 + i)
+    if wl["ip"]:  # IP-Adapter processors at the 16 cross-attention sites + CN processors on the ControlNets (modules/ip_adapter.py:95-134)
+        from types import SimpleNamespace
+        from controlanimate_amd.ip_adapter import IPAdapter
+        ip = IPAdapter(SimpleNamespace(unet=unet), None, None, device, num_tokens=4)
+        g = torch.Generator().manual_seed(77)
+        for proc in unet.attn_processors.values():
+            if hasattr(proc, "to_k_ip"):
+                for lin in (proc.to_k_ip, proc.to_v_ip):
+                    lin.weight.data.copy_((torch.randn(lin.weight.shape, generator=g) * lin.weight.shape[1] ** -0.5).to(device))
+        ip.set_scale(0.4)
+        if nets:
+            ip.set_ip_adapter_4controlanimate(SimpleNamespace(controlnet=SimpleNamespace(nets=nets)))
     unet.prepare(device, dtype)
     for n in nets:
         n.prepare(device, dtype)
@@ -270,6 +323,27 @@ def usable_cores() -> int:
     except Exception:
         pass
     return max(1, min(n, 32))  # >32 threads only adds synchronisation overhead at these op sizes
+
+
+def cpu_baseline_config2(threads: int):
+    """ONE full config-2 denoise step ("config 1 in full and one step of config 2") with the fp32 oracle:
+    ControlNet (B = 32) + UNet3D v2 (b = 2, f = 16, 64x64 latents) on the host cores.  ~44.6 TFLOP."""
+    from oracle.controlnet import ControlNetConfig, init_controlnet_weights, multi_controlnet_residuals
+    from oracle.unet3d import UNet3DConfig, init_unet3d_weights, unet3d_forward
+    torch.set_num_threads(threads)
+    ucfg, ccfg = UNet3DConfig.v2(), ControlNetConfig()
+    uw, cw = init_unet3d_weights(ucfg, seed=0), init_controlnet_weights(ccfg, seed=1)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 16, 64, 64, generator=g)
+    ehs = torch.randn(2, 77, 768, generator=g) * 0.5
+    hints = torch.rand(32, 3, 512, 512, generator=g)
+    with torch.no_grad():
+        t0 = time.time()
+        down, mid = multi_controlnet_residuals([cw], ccfg, x, 999, ehs, 16, [hints], [1.0], guess_mode=False)
+        unet3d_forward(uw, ucfg, x, 999, ehs, down, mid)
+        dt = time.time() - t0
+    return {"sec_per_step": dt, "tflops": 44.6 / dt, "frames_per_sec": 16.0 / (20 * dt), "cores": threads,
+            "sample": "1 oracle denoise step of BASELINE config 2 (ControlNet B=32 + UNet3D b=2 f=16 64x64 latents, fp32)"}
 
 
 def cpu_baseline(threads: int):
@@ -294,14 +368,14 @@ def cpu_baseline(threads: int):
                       "config-2 step is 44.6 TFLOP => FLOP-scaled estimate %.1f s/step" % (dt * 44.6 / 4.09)}
 
 
-def time_vae(args, device, dtype):
+def time_vae(wl, device, dtype):
     """ms per window for encoding / decoding all frames with the HIP AutoencoderKL."""
     from controlanimate_amd.vae import AutoencoderKL
     torch.manual_seed(0)
     vae = AutoencoderKL.from_config().to(device).prepare(device, dtype)
     g = torch.Generator().manual_seed(4321)
-    imgs = (torch.rand(args.frames, 3, args.size, args.size, generator=g) * 2 - 1).to(device)
-    lat = torch.randn(args.frames, 4, args.size // 8, args.size // 8, generator=g).to(device)
+    imgs = (torch.rand(wl["frames"], 3, wl["height"], wl["width"], generator=g) * 2 - 1).to(device)
+    lat = torch.randn(wl["frames"], 4, wl["height"] // 8, wl["width"] // 8, generator=g).to(device)
     out = {}
     for name, fn in (("encode_ms_per_window", lambda: vae.encode_moments(imgs)), ("decode_ms_per_window", lambda: vae.decode(lat))):
         fn()
@@ -322,7 +396,7 @@ def plumbing_only(args):
     rank, world, _ = WS.init_distributed()
     g = torch.Generator().manual_seed(11)
     arenas = [torch.randint(0, 255, (1 << 20,), dtype=torch.uint8, generator=g) if rank == 0 else torch.zeros(1 << 20, dtype=torch.uint8)
-              for _ in range(1 + args.controlnets)]
+              for _ in range(1 + CONFIGS[args.config]['controlnets'])]
     ref = int(arenas[0][:4096].to(torch.int64).sum()) if rank == 0 else None
     bytes_bcast = WS.broadcast_weights(arenas)
     if world > 1:
@@ -363,8 +437,21 @@ def main():
     from controlanimate_amd import kernels as K
     from controlanimate_amd import window_shard as WS
     from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
-    from controlanimate_amd.schedulers import DiffusersLCMScheduler
+    from controlanimate_amd.schedulers import get_scheduler
     from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+
+    wl = dict(CONFIGS[args.config])
+    custom = False
+    if args.frames is not None:
+        wl["frames"], custom = args.frames, True
+    if args.size is not None:
+        wl["height"] = wl["width"] = args.size
+        custom = True
+    if args.controlnets is not None:
+        wl["controlnets"], custom = args.controlnets, True
+    base = CONFIGS[args.config]
+    scale = (wl["frames"] / base["frames"]) * (wl["height"] * wl["width"]) / (base["height"] * base["width"])  # (attention terms scale slightly faster)
+    steps_per_window = wl["steps"]
 
     rank, world, local_rank = WS.init_distributed()
     if not torch.cuda.is_available():
@@ -377,46 +464,57 @@ def main():
     timer = KernelTimer()
     if not args.no_roofline:
         timer.install()
-    unet, nets = build_models(args, device, dtype)
+    unet, nets = build_models(wl, device, dtype)
     bytes_bcast = WS.broadcast_weights([unet.arena.buffer] + [n.arena.buffer for n in nets])
 
-    f, hw = args.frames, args.size // 8
+    f, lh, lw = wl["frames"], wl["height"] // 8, wl["width"] // 8
     g = torch.Generator().manual_seed(1234)
-    latents = torch.randn(1, 4, f, hw, hw, generator=g).to(device)
-    pos = (torch.randn(1, 77, 768, generator=g) * 0.5).to(device)
-    neg = (torch.randn(1, 77, 768, generator=g) * 0.5).to(device)
-    prompt = torch.cat([neg, pos]).contiguous()
-    guidance = 1.1
+    latents = torch.randn(1, 4, f, lh, lw, generator=g).to(device)
+    L = 81 if wl["ip"] else 77   # IP-Adapter: 4 image tokens appended to both halves (controlanimation_pipeline.py:698-710)
+    pos = (torch.randn(1, L, 768, generator=g) * 0.5).to(device)
+    neg = (torch.randn(1, L, 768, generator=g) * 0.5).to(device)
+    guidance = wl["guidance"]
+    rep = 2 if guidance > 1.0 else 1
+    prompt = torch.cat([neg, pos]).contiguous() if rep == 2 else pos.contiguous()
+    cn_single = wl["guess_mode"] or rep == 1          # ControlNet input selection (:811-813)
+    cn_prompt = pos.contiguous() if cn_single else prompt
     cn = None
     if nets:
         cn = MultiControlNetResidualsPipeline([f"synthetic-canny-{i}" for i in range(len(nets))], [1.0] * len(nets), use_lcm=False,
                                               controlnets=nets, device=device)
-        hints = torch.rand(f, 3, args.size, args.size, generator=g)
-        cn.prep_control_images([h for h in hints], do_classifier_free_guidance=True, guess_mode=False)
-    sched = DiffusersLCMScheduler(**NOISE_SCHEDULER_KWARGS)
-    sched.set_timesteps(STEPS_PER_WINDOW)
+        hints = torch.rand(f, 3, wl["height"], wl["width"], generator=g)
+        cn.prep_control_images([h for h in hints], do_classifier_free_guidance=rep == 2, guess_mode=wl["guess_mode"])
+    sched = get_scheduler(wl["scheduler"], **NOISE_SCHEDULER_KWARGS)
+    sched.set_timesteps(steps_per_window)
     cpad = unet.conv_in.cin_pad
-    noise_dev = torch.randn(1, 4, f, hw, hw, generator=g).to(device)
+    noise_dev = torch.randn(1, 4, f, lh, lw, generator=g).to(device)
 
-    state = {"latents": latents}
-    x_static = torch.empty((2 * f, hw, hw, cpad), device=device, dtype=dtype)
+    state = {"latents": latents * float(getattr(sched, "init_noise_sigma", 1.0))}
+    x_static = torch.empty((rep * f, lh, lw, cpad), device=device, dtype=dtype)
     t_static = torch.zeros(1, device=device, dtype=torch.float32)
     graph_state = {"graph": None, "eps": None}
     overlap = {"on": not args.no_overlap}
+    window_refresh = {"gemms": 0}
 
     def model_eps(t):
         """ControlNet residuals + UNet3D eps for the contents of x_static at (device) timestep t."""
         down = mid = None
         if cn is not None:
+            x_cn = x_static[:f] if (cn_single and rep == 2) else x_static
             if overlap["on"]:  # ControlNet beside the UNet encoder on a second stream (as the pipeline does)
-                down = cn.residuals_nhwc_async(x_static, t, prompt, False)
+                down = cn.residuals_nhwc_async(x_cn, t, cn_prompt, wl["guess_mode"])
             else:
-                down, mid = cn.residuals_nhwc(x_static, t, prompt, False)
-        return unet.forward_nhwc(x_static, 2, f, t, prompt, down, mid)
+                down, mid = cn.residuals_nhwc(x_cn, t, cn_prompt, wl["guess_mode"])
+        return unet.forward_nhwc(x_static, rep, f, t, prompt, down, mid)
 
     def step(i):
-        idx = i % STEPS_PER_WINDOW
-        K.latents_to_nhwc(state["latents"], cpad, 2, sched.input_scale(idx), dtype, out=x_static)
+        idx = i % steps_per_window
+        if idx == 0 and graph_state["graph"] is not None:
+            # a new window: its per-window work (hint embedding of the control frames, text / IP K/V of every
+            # cross-attention site) is redone here, in place, inside the timed region -- the graph replays only reuse it
+            # (eager steps redo nothing: the pipeline's first eager step of a window fills these caches the same way)
+            window_refresh["gemms"] = unet.refresh_window_caches() + sum(n.refresh_window_caches() for n in nets)
+        K.latents_to_nhwc(state["latents"], cpad, rep, sched.input_scale(idx), dtype, out=x_static)
         if graph_state["graph"] is not None:
             t_static.fill_(float(sched.timesteps[idx]))
             graph_state["graph"].replay()
@@ -424,9 +522,10 @@ def main():
         else:
             eps = model_eps(sched.timesteps[idx])
         coef, clip = sched.coefficients(idx)
-        state["latents"], _ = K.cfg_scheduler_step(eps, 2, guidance, state["latents"], noise_dev, coef, clip)
-        if idx == STEPS_PER_WINDOW - 1:
-            state["latents"] = latents  # next window
+        state["latents"], _ = K.cfg_scheduler_step(eps, rep, guidance if rep == 2 else 1.0, state["latents"],
+                                                   noise_dev if sched.needs_noise else None, coef, clip)
+        if idx == steps_per_window - 1:
+            state["latents"] = latents * float(getattr(sched, "init_noise_sigma", 1.0))  # next window
 
     def capture_graph():
         model_eps(t_static)  # warm: prompt K/V and hint-embedding caches, allocator pools
@@ -454,12 +553,17 @@ def main():
     barrier()
     timer.enabled = False  # per-launch HIP events cost ~7% of a step: they are taken in a second pass
     torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ev[i][0].record()
         step(args.warmup + i)
+        ev[i][1].record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     timer.enabled = False
     roof_elapsed = elapsed
     if not args.no_roofline:
@@ -480,7 +584,7 @@ def main():
         graph_state["graph"] = gr
     vae_ms = None
     if not args.no_vae and world == 1:  # single-GPU runs only: the other ranks of a scaling run must not wait for it
-        vae_ms = time_vae(args, device, dtype)
+        vae_ms = time_vae(wl, device, dtype)
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -489,27 +593,37 @@ def main():
         raise SystemExit("non-finite latents after the timed region")
 
     sec_per_step = elapsed / args.steps
-    fps = world * f / (STEPS_PER_WINDOW * sec_per_step)
-    unet_tflop = 35.53 * (f / 16) * (args.size / 512) ** 2  # BASELINE.md section 3 (config 2; attention terms scale slightly faster)
-    cn_tflop = 9.07 * (f / 16) * (args.size / 512) ** 2
-    step_tflop = unet_tflop + len(nets) * cn_tflop
+    fps = world * f / (steps_per_window * sec_per_step)
+    # per ControlNet: the reference feeds it b*f images, or f in guess mode / without CFG
+    cn_tflop = wl["cn_tflop"] * scale
+    step_tflop = wl["unet_tflop"] * scale + len(nets) * cn_tflop
+    f_new = f - wl["overlap"]
     out = {
         "metric": "frames_per_sec", "value": round(fps, 4), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * sec_per_step, 3),
-        "sec_per_denoise_step": round(sec_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "sec_per_denoise_step": round(sec_per_step, 5), "ms_per_step_median_hipevent": round(median_ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"SD1.5+mm_sd_v15_v2 UNet3D, {f} frames {args.size}x{args.size}, {STEPS_PER_WINDOW} LCM steps/window, "
-                               f"CFG g={guidance} (batch 2), {len(nets)} ControlNet(s); one window per GPU",
-                   "frames_per_window": f, "steps_per_window": STEPS_PER_WINDOW, "controlnets": len(nets),
+        "config": {"workload": wl["name"] + (" [size/frames/controlnets overridden on the command line]" if custom else "") + "; one window per GPU",
+                   "baseline_config": args.config, "frames_per_window": f, "height": wl["height"], "width": wl["width"],
+                   "steps_per_window": steps_per_window, "scheduler": wl["scheduler"], "guidance_scale": guidance, "cfg_batch": rep,
+                   "controlnets": len(nets), "controlnet_batch": (f if cn_single else rep * f) if nets else 0, "guess_mode": wl["guess_mode"],
+                   "ip_adapter_tokens": 4 if wl["ip"] else 0, "overlap_length": wl["overlap"],
                    "parallelism": f"window-shard x{world}" if world > 1 else "single GPU",
                    "weight_broadcast_bytes": bytes_bcast},
+        # steady state of the sliding window (scripts/vid2vid.py:168-189): a window re-feeds `overlap_length` frames, so it
+        # contributes frame_count - overlap_length NEW frames; equal to `value` when the config has no overlap
+        "frames_per_sec_steady_state": round(world * f_new / (steps_per_window * sec_per_step), 4),
+        "per_window_work_in_timed_region": ("hint embedding + text/IP K/V recomputed in place at every window start "
+                                            f"({window_refresh['gemms']} launches groups)" if use_graph else
+                                            "eager run: nothing is cached outside the timed region except across the steps of a window"),
         "step_algorithmic_tflop": round(step_tflop, 2),
         "step_mfma_frac": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
         "vae": None if vae_ms is None else {
             **vae_ms,
-            "frames_per_sec_end_to_end": round(world * f / (STEPS_PER_WINDOW * sec_per_step + 1e-3 * (vae_ms["encode_ms_per_window"] + vae_ms["decode_ms_per_window"])), 4),
+            "frames_per_sec_end_to_end": round(world * f / (steps_per_window * sec_per_step + 1e-3 * (vae_ms["encode_ms_per_window"] + vae_ms["decode_ms_per_window"])), 4),
             "note": "SD1.5 AutoencoderKL on the same kernels, random weights; encode + decode of all frames of one window "
-                    "(brackets the 20 denoise steps; not part of `value`)"},
+                    "(brackets the denoise steps; not part of `value`)"},
         "hip_graph": bool(use_graph),
         "controlnet_second_stream": bool(not args.no_overlap and nets),
     }
@@ -519,10 +633,12 @@ def main():
             dom = max(agg, key=lambda k: agg[k]["ms"])
             d = agg[dom]
             rname = rocprof_kernel_name(dom, args.dtype)
-            out["roofline"] = {"bound": "mfma", "kernel": f"k_gemm_dma<{dom}>", "rocprof_name": rname + "...>" if rname else None,
+            traffic, traffic_src = pmc_traffic(rname, "config%d" % args.config if not custom else "custom", args.dtype)
+            out["roofline"] = {"bound": "mfma", "kernel": (f"k_gemm_pp2<{dom}>" if dom.endswith("pp128x320") else f"k_gemm_dma<{dom}>"), "rocprof_name": rname + "...>" if rname else None,
                                "achieved": round(d["tflops"], 2), "peak": PEAK_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(rname),
-                               "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/round1_pmc_traffic.json)",
+                               "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+                               "traffic_unit": ("HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s: same workload and dtype)" % traffic_src)
+                               if traffic is not None else "null: no committed PMC summary for this workload / dtype",
                                "launches": d["launches"], "avg_launch_us": round(d["avg_us"], 2),
                                "flop_per_launch": round(d["flops"] / d["launches"], 1),
                                "share_of_step_time": round(d["ms"] * 1e-3 / roof_elapsed, 4),
@@ -536,6 +652,8 @@ def main():
             print(row, file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(usable_cores())
+        if args.cpu_baseline_config2:
+            out["cpu_baseline"]["config2_step"] = cpu_baseline_config2(usable_cores())
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

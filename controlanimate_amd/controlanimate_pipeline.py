@@ -8,7 +8,14 @@ and the config keys it reads (inference_config_path / motion_module / use_lcm / 
 cond_scale / scheduler / use_ipadapter / seed / width / height / steps / strength / guidance_scale /
 frame_count / overlaps / epoch / guess_mode / ipa_scale / use_img2img ...).
 
-Models are injected (there is no network for Hugging Face downloads):
+`ControlAnimatePipeline(config)` builds everything from the LOCAL paths the config names, step for step as the reference
+constructor does (tokenizer / text encoder / VAE / UNet from `pretrained_model_path/<subfolder>` or `vae_path` /
+`pretrained_lcm_model_path`, ControlNets by name from local directories or the Hugging Face cache, scheduler by name with
+the `noise_scheduler_kwargs` of `inference_config_path`, IP-Adapter from models/IP-Adapter, `load_weights` for the motion
+module / DreamBooth / LoRAs, the easynegative textual inversion when its file exists, `maybe_convert_prompt`).  There is
+no network: a model that is not on disk is an error naming the places that were searched.
+
+Alternatively models are injected:
     components = dict(unet=UNet3DConditionModel, controlnets=[ControlNetModel...],
                       vae=None | controlanimate_amd.vae.AutoencoderKL | any diffusers-style VAE,
                       text_encoder=None | controlanimate_amd.clip.CLIPTextModel, tokenizer=None | CLIPTokenizer,
@@ -38,10 +45,53 @@ def _get(cfg, key, default=None):
     return getattr(cfg, key, default) if hasattr(cfg, key) else default
 
 
+IP_IMAGE_ENCODER_PATH = "models/IP-Adapter/models/image_encoder/"   # modules/controlanimate_pipeline.py:80
+IP_CKPT_PATH = "models/IP-Adapter/models/ip-adapter_sd15.bin"       # :81
+TI_PATH = "models/TI/easynegative.safetensors"                       # :118
+
+
+def components_from_config(config) -> Dict[str, Any]:
+    """The model-building half of the reference constructor (modules/controlanimate_pipeline.py:27-48, 77-84) on local files."""
+    import yaml
+    from . import local_models as LM
+    from .unet import UNet3DConditionModel
+    with open(_get(config, "inference_config_path")) as fh:
+        inference_config = yaml.safe_load(fh)
+    use_lcm = bool(_get(config, "use_lcm", 0))
+    base = _get(config, "pretrained_model_path")
+    comp: Dict[str, Any] = dict(noise_scheduler_kwargs=inference_config.get("noise_scheduler_kwargs"), from_config=True)
+    comp["tokenizer"] = LM.load_tokenizer(base)
+    comp["text_encoder"] = LM.load_text_encoder(base)
+    comp["vae"] = LM.load_vae(base, _get(config, "vae_path", "") or "")
+    if not use_lcm:
+        comp["unet"] = UNet3DConditionModel.from_pretrained_2d(base, subfolder="unet", use_safetensors=_has_safetensors(base, "unet"),
+                                                               unet_additional_kwargs=inference_config["unet_additional_kwargs"])
+    else:
+        comp["unet"] = UNet3DConditionModel.from_pretrained_2d(_get(config, "pretrained_lcm_model_path"), subfolder="unet", use_safetensors=True,
+                                                               unet_additional_kwargs=inference_config["unet_additional_kwargs"])
+    names = _get(config, "controlnets", None)
+    comp["controlnets"] = [LM.load_controlnet(n) for n in names] if names else []
+    if bool(_get(config, "use_ipadapter", 0)):
+        comp["image_encoder"] = LM.load_image_encoder(IP_IMAGE_ENCODER_PATH)
+        comp["ip_adapter_ckpt"] = LM.read_checkpoint(IP_CKPT_PATH)
+    return comp
+
+
+def _has_safetensors(base, sub) -> bool:
+    import os
+    from .local_models import resolve_model_dir
+    return os.path.isfile(os.path.join(resolve_model_dir(base, sub), "diffusion_pytorch_model.safetensors"))
+
+
 class ControlAnimatePipeline:
-    def __init__(self, config, components: Dict[str, Any], device="cuda"):
+    def __init__(self, config, components: Optional[Dict[str, Any]] = None, device=None):
         self.use_lcm = bool(_get(config, "use_lcm", 0))
-        self.device = torch.device(device)
+        # the reference hard-wires "cuda"; without a GPU the object can still be built (files read, weights fused, prompts
+        # converted) but animate() fails loudly: the execution path has no CPU fallback
+        self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        built_here = components is None
+        if built_here:
+            components = components_from_config(config)
         unet = components["unet"]
         nets = components.get("controlnets") or []
         names = list(_get(config, "controlnets", None) or [f"controlnet-{i}" for i in range(len(nets))])
@@ -61,14 +111,36 @@ class ControlAnimatePipeline:
             self.pipeline.ip_adapter = ip
             if self.multicontrolnetresiduals_pipeline is not None:
                 ip.set_ip_adapter_4controlanimate(self.multicontrolnetresiduals_pipeline)
+        if built_here:  # reference :87-106: motion module, DreamBooth checkpoint, LoRAs, motion LoRAs
+            from .weight_ingest import load_weights
+            lora_paths = _get(config, "lora_model_paths", "") or ""
+            kw = {} if self.use_lcm else dict(dreambooth_model_path=_get(config, "dreambooth_path", "") or "",
+                                              lora_model_path=lora_paths, lora_alpha=_get(config, "lora_weights", [0.8]))
+            load_weights(self.pipeline, motion_module_path=_get(config, "motion_module", "") or "",
+                         motion_module_lora_configs=_get(config, "motion_module_lora_configs", []) or [], **kw)
         # the reference halves everything unless native LCM (:108-110,115); here fp16 is the activation
         # dtype of the packed weights in both cases, selected at prepare() time.
-        unet.prepare(self.device, components.get("dtype", torch.float16))
-        for n in nets:
-            n.prepare(self.device, components.get("dtype", torch.float16))
+        self._dtype = components.get("dtype", torch.float16)
+        self._prepared = False
+        import os
+        if built_here and os.path.isfile(TI_PATH):  # :118 (the reference fails without the file; it ships it in models/TI)
+            self.pipeline.load_textual_inversion(TI_PATH, token="easynegative")
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            self._prepare_models()
         self.prompt = _get(config, "prompt", "")
         self.n_prompt = _get(config, "n_prompt", "")
+        if self.pipeline.tokenizer is not None:  # :120-121
+            self.prompt = self.pipeline.maybe_convert_prompt(self.prompt, self.pipeline.tokenizer)
+            self.n_prompt = self.pipeline.maybe_convert_prompt(self.n_prompt, self.pipeline.tokenizer)
         self._embeds = components.get("prompt_embeds"), components.get("negative_prompt_embeds")
+
+    def _prepare_models(self):
+        """Packs the weights into their device arenas (needs the HIP device; there is no CPU path)."""
+        models = [self.pipeline.unet] + (list(self.multicontrolnetresiduals_pipeline.controlnets) if self.multicontrolnetresiduals_pipeline else [])
+        models += [m for m in (self.pipeline.vae, self.pipeline.text_encoder) if hasattr(m, "prepare") and getattr(m, "arena", 0) is None]
+        for m in models:
+            m.prepare(self.device, self._dtype)
+        self._prepared = True
 
     def _encode_plain(self, prompt: str) -> torch.Tensor:
         tok = self.pipeline.tokenizer
@@ -86,6 +158,8 @@ class ControlAnimatePipeline:
 
     def animate(self, input_frames, last_output_frames, config, image_prompt_embeds=None, uncond_image_prompt_embeds=None,
                 **extra):
+        if not self._prepared:
+            self._prepare_models()
         seed = int(_get(config, "seed", 0))
         torch.manual_seed(seed)                                   # global RNG: in-tree LCM noise (:129)
         self.generator = torch.Generator(device="cpu").manual_seed(seed)  # initial latents (:130)

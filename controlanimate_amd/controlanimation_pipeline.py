@@ -51,6 +51,10 @@ class ControlAnimationPipeline:
         self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
         self.vae_scale_factor = 8
         self.ip_adapter = None
+        from .local_models import VaeImageProcessor  # reference :159-163
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)
+        self.control_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True, do_normalize=False)
+        self._pending_lora: List[dict] = []
         self.device = torch.device("cuda")
         self.last_step_times: List[float] = []
         self.record_eps = False      # True: keep every step's raw UNet eps ([rep,4,f,h,w] fp32, CPU) in `eps_history` (parity tests)
@@ -67,6 +71,62 @@ class ControlAnimationPipeline:
     @property
     def _execution_device(self):
         return self.device
+
+    # ---- loader mixins the reference inherits from diffusers and calls on the pipeline -------------------------------
+    def maybe_convert_prompt(self, prompt, tokenizer=None):
+        """TextualInversionLoaderMixin.maybe_convert_prompt (used at modules/controlanimate_pipeline.py:120-121)."""
+        from .local_models import maybe_convert_prompt
+        return maybe_convert_prompt(prompt, tokenizer if tokenizer is not None else self.tokenizer)
+
+    def load_textual_inversion(self, pretrained_model_name_or_path: str, token: Optional[str] = None, **_):
+        """TextualInversionLoaderMixin.load_textual_inversion for one embedding file (:118): the (multi-vector)
+        embedding becomes new tokenizer entries token, token_1, ... and new rows of the text encoder's token table."""
+        from .local_models import read_textual_inversion
+        if self.tokenizer is None or self.text_encoder is None:
+            raise RuntimeError("load_textual_inversion needs a tokenizer and a text_encoder")
+        tokens, emb = read_textual_inversion(pretrained_model_name_or_path, token)
+        vocab = self.tokenizer.get_vocab()
+        clash = [t for t in tokens if t in vocab]
+        if clash:
+            raise ValueError(f"token(s) {clash} already in the tokenizer vocabulary; pass a different `token`")
+        self.tokenizer.add_tokens(tokens)
+        table = self.text_encoder.text_model.embeddings.token_embedding
+        if emb.shape[1] != table.weight.shape[1]:
+            raise ValueError(f"embedding width {emb.shape[1]} != text encoder width {table.weight.shape[1]}")
+        old = table.weight.data
+        new_rows = len(self.tokenizer) - old.shape[0]
+        grown = torch.cat([old, torch.zeros(max(new_rows, 0), old.shape[1], dtype=old.dtype, device=old.device)])
+        for t, e in zip(tokens, emb):
+            grown[self.tokenizer.convert_tokens_to_ids(t)] = e.to(grown)
+        table.weight = torch.nn.Parameter(grown, requires_grad=False)
+        table.num_embeddings = grown.shape[0]
+        if hasattr(self.text_encoder, "config"):
+            self.text_encoder.config.vocab_size = grown.shape[0]
+        if getattr(self.text_encoder, "arena", None) is not None:
+            self.text_encoder.prepare(self.device)  # repack
+        return tokens
+
+    def load_lora_weights(self, pretrained_model_name_or_path_or_dict, **_):
+        """LoraLoaderMixin.load_lora_weights (animatediff/utils/util.py:155): the state dict is kept until fuse_lora."""
+        from .weight_ingest import read_checkpoint
+        sd = pretrained_model_name_or_path_or_dict
+        self._pending_lora.append(dict(sd) if isinstance(sd, dict) else read_checkpoint(sd))
+
+    def fuse_lora(self, lora_scale: float = 1.0, **_):
+        """LoraLoaderMixin.fuse_lora (util.py:156): W += scale * alpha / rank * up @ down on the UNet and, when the
+        file carries them and a fusable text encoder is attached, on the text encoder."""
+        from .weight_ingest import fuse_lora, fuse_lora_text_encoder, lora_text_encoder_keys
+        for sd in self._pending_lora:
+            fuse_lora(self.unet, sd, lora_scale=float(lora_scale))
+            if lora_text_encoder_keys(sd):
+                if isinstance(self.text_encoder, torch.nn.Module):
+                    fuse_lora_text_encoder(self.text_encoder, sd, lora_scale=float(lora_scale))
+                else:
+                    logger.warning("text-encoder LoRA tensors skipped: no fusable text_encoder attached")
+        self._pending_lora = []
+        for m in (self.unet, self.text_encoder):
+            if m is not None and getattr(m, "arena", None) is not None:
+                m.prepare(self.device)
 
     def enable_xformers_memory_efficient_attention(self):
         """No-op: the flash attention kernel is the only attention path (no xformers)."""
@@ -216,6 +276,13 @@ class ControlAnimationPipeline:
                                            use_img2img, input_latents, last_output_latents)
         latents = latents.to(device=device, dtype=torch.float32).contiguous()
         f = latents.shape[2]
+        step_range = kwargs.get("step_range")
+        if step_range is not None:
+            # parity-test hook ("teacher forcing"): run only loop iterations lo..hi-1 of the schedule, starting from the
+            # given `latents` -- a step is then compared with the reference on IDENTICAL inputs
+            lo, hi = step_range
+            timesteps = timesteps[lo:hi]
+            first += lo
 
         w_embedding = get_w_embedding(torch.tensor([float(guidance_scale)]), embedding_dim=256).to(device) if use_lcm else None
 

@@ -118,6 +118,17 @@ class ControlNetModel(HipModelMixin, nn.Module):
         self._hint_key = (controlnet_cond, controlnet_cond._version)
         return self._hint_emb
 
+    def refresh_window_caches(self) -> int:
+        """HipModelMixin.refresh_window_caches + the hint embedding of the current control images (in place)."""
+        n = super().refresh_window_caches()
+        if self._hint_key is not None and self._hint_emb is not None:
+            ce = self.controlnet_cond_embedding
+            cond = self._hint_key[0]
+            nhwc = K.ncfhw_to_nhwc(cond.to(self._hint_emb.device).unsqueeze(2), ce.conv_in.cin_pad, self.act_dtype)
+            self._hint_emb.copy_(ce(nhwc))
+            n += 1
+        return n
+
     def prepare(self, device=None, dtype=None):
         self._hint_key = self._hint_emb = None
         return super().prepare(device, dtype)

@@ -47,9 +47,10 @@ class MultiControlNetResidualsPipeline:
                  annotators: Optional[Dict[str, Callable]] = None):
         self.controlnet_names = list(hf_controlnet_names)
         if controlnets is None:
-            raise RuntimeError(
-                "no ControlNet weights: pass `controlnets=[ControlNetModel, ...]` (checkpoint loading from the "
-                "Hugging Face hub needs network access, which this build does not have)")
+            # the reference's own constructor: ControlNetModel.from_pretrained(name) per name (:32-33) -- here from local
+            # directories / the Hugging Face cache (there is no network; a missing model says where it was looked for)
+            from .local_models import load_controlnet
+            controlnets = [load_controlnet(n) for n in self.controlnet_names]
         if len(controlnets) != len(self.controlnet_names):
             raise ValueError("one ControlNetModel per name expected")
         self.controlnets = list(controlnets)

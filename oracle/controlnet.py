@@ -2,8 +2,13 @@
 
 Test infrastructure only.  diffusers is a THIRD-PARTY dependency that is absent from
 /root/reference (pinned at env.yml:120) and not installable here: this file restates the published
-algorithm -- PARITY UNPINNED for the ControlNet arithmetic itself.  What the
-reference does own and this file follows:
+algorithm.  PINNING: the encoder + mid block are the SD1.5 UNet encoder, whose arithmetic the
+reference carries itself (animatediff/models/unet_blocks.py:173-523 with use_motion_module=False, one frame per image):
+tests/golden/make_controlnet_golden.py assembles a ControlNet from those reference blocks and
+tests/test_oracle_golden.py::test_controlnet_oracle_matches_reference_blocks checks this file against it (reduced and
+full SD1.5 width, plain / guess-mode scaling, CNAttnProcessor2_0 token strip; <= 3e-5).  Still restatement-only: the 21
+plain convolutions around the blocks (conv_in, hint embedding, 13 zero-convs), the logspace guess-mode scales and the sum
+over nets of MultiControlNetModel.  What the reference owns besides the blocks and this file follows:
   modules/controlresiduals_pipeline.py:278-316   rearranges, prompt repetition quirk, (b f) batching
   animatediff/utils/convert_from_ckpt.py:514-554 checkpoint key names (controlnet_cond_embedding.*,
                                                  controlnet_down_blocks.0-11, controlnet_mid_block)

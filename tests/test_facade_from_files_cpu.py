@@ -1,0 +1,171 @@
+"""CPU: `ControlAnimatePipeline(config)` exactly as scripts/vid2vid.py:152 calls it -- every model comes from local files
+named by the config (VERDICT r1 item 8 / SURVEY 8b).  A temporary directory holds tiny checkpoints in the on-disk formats the
+reference reads: SD-style `unet/ vae/ text_encoder/ tokenizer/` subfolders, a ControlNet directory, a motion-module .ckpt,
+an inference yaml, a kohya LoRA and the easynegative-style textual inversion."""
+import json
+import os
+
+import pytest
+import torch
+import yaml
+from safetensors.torch import save_file
+
+BOC = (32, 64, 128, 128)
+
+
+def _write_tokenizer(d):
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
+    cs, n = bs[:], 0
+    for b in range(256):  # the GPT-2 / CLIP byte -> printable unicode table
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    chars = [chr(c) for c in cs]
+    vocab = {}
+    for c in chars:
+        vocab[c] = len(vocab)
+    for c in chars:
+        vocab[c + "</w>"] = len(vocab)
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    os.makedirs(d)
+    json.dump(vocab, open(os.path.join(d, "vocab.json"), "w"))
+    open(os.path.join(d, "merges.txt"), "w").write("#version: 0.2\n")
+    return len(vocab)
+
+
+@pytest.fixture()
+def model_tree(tmp_path, monkeypatch):
+    from controlanimate_amd.clip import CLIPTextModel
+    from controlanimate_amd.configs import INFERENCE_V2, NOISE_SCHEDULER_KWARGS, controlnet_config, unet_config
+    from controlanimate_amd.controlnet import ControlNetModel
+    from controlanimate_amd.unet import UNet3DConditionModel
+    from controlanimate_amd.vae import AutoencoderKL
+    torch.manual_seed(0)
+    root = tmp_path
+    base = root / "sd15"
+    # --- UNet: the 2-D SD checkpoint (no motion modules) + its config.json with the 2-D block names
+    unet = UNet3DConditionModel.from_config(unet_config("v2", block_out_channels=BOC))
+    cfg2d = {k: v for k, v in unet_config("v2", block_out_channels=BOC).items() if k not in INFERENCE_V2}
+    cfg2d.update(down_block_types=["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], up_block_types=["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3,
+                 _class_name="UNet2DConditionModel")
+    os.makedirs(base / "unet")
+    json.dump(cfg2d, open(base / "unet" / "config.json", "w"))
+    sd2d = {k: v.detach().clone() for k, v in unet.state_dict().items() if "motion_modules" not in k}
+    torch.save(sd2d, base / "unet" / "diffusion_pytorch_model.bin")
+    mm = {k: (torch.randn_like(v) * 0.02) for k, v in unet.state_dict().items() if "motion_modules" in k}
+    torch.save({"state_dict": mm}, root / "mm_tiny.ckpt")
+    # --- VAE
+    vae_cfg = dict(block_out_channels=(32, 64), layers_per_block=1, latent_channels=4, norm_num_groups=32,
+                   down_block_types=["DownEncoderBlock2D"] * 2, up_block_types=["UpDecoderBlock2D"] * 2)
+    vae = AutoencoderKL.from_config(vae_cfg)
+    os.makedirs(base / "vae")
+    json.dump(dict(vae_cfg, _class_name="AutoencoderKL"), open(base / "vae" / "config.json", "w"))
+    save_file({k: v.detach().contiguous() for k, v in vae.state_dict().items()}, str(base / "vae" / "diffusion_pytorch_model.safetensors"))
+    # --- tokenizer + text encoder (hidden 768 so that the 8 x 768 textual inversion fits; 1 layer)
+    nvocab = _write_tokenizer(str(base / "tokenizer"))
+    te_cfg = dict(vocab_size=nvocab, hidden_size=768, intermediate_size=64, num_hidden_layers=1, num_attention_heads=12, max_position_embeddings=77)
+    te = CLIPTextModel.from_config(te_cfg)
+    os.makedirs(base / "text_encoder")
+    json.dump(te_cfg, open(base / "text_encoder" / "config.json", "w"))
+    save_file({k: v.detach().contiguous() for k, v in te.state_dict().items()}, str(base / "text_encoder" / "model.safetensors"))
+    # --- one ControlNet, addressed by its (local) name
+    cn = ControlNetModel.from_config(controlnet_config(block_out_channels=BOC))
+    os.makedirs(root / "cn-canny")
+    json.dump(dict(controlnet_config(block_out_channels=BOC), _class_name="ControlNetModel"), open(root / "cn-canny" / "config.json", "w"))
+    save_file({k: v.detach().contiguous() for k, v in cn.state_dict().items()}, str(root / "cn-canny" / "diffusion_pytorch_model.safetensors"))
+    # --- inference yaml, LoRA, textual inversion (relative path models/TI/..., as the reference hard-codes it)
+    yaml.safe_dump(dict(unet_additional_kwargs=dict(INFERENCE_V2), noise_scheduler_kwargs=dict(NOISE_SCHEDULER_KWARGS)),
+                   open(root / "inference-v2.yaml", "w"))
+    q = "down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q"
+    lora = {f"lora_unet_{q}.lora_down.weight": torch.randn(4, 32) * 0.1, f"lora_unet_{q}.lora_up.weight": torch.randn(32, 4) * 0.1,
+            f"lora_unet_{q}.alpha": torch.tensor(4.0)}
+    save_file(lora, str(root / "style_lora.safetensors"))
+    os.makedirs(root / "models" / "TI")
+    ti = torch.randn(8, 768) * 0.01
+    save_file({"emb_params": ti}, str(root / "models" / "TI" / "easynegative.safetensors"))
+    monkeypatch.chdir(root)
+    return dict(root=root, base=str(base), unet_sd=sd2d, mm=mm, lora=lora, ti=ti, q_path=q, nvocab=nvocab)
+
+
+def _config(tree, **over):
+    from controlanimate_amd.local_models import Config
+    cfg = Config(inference_config_path=str(tree["root"] / "inference-v2.yaml"), motion_module=str(tree["root"] / "mm_tiny.ckpt"), use_lcm=0,
+                 pretrained_model_path=tree["base"], vae_path="", pretrained_lcm_model_path="", controlnets=[str(tree["root"] / "cn-canny")],
+                 cond_scale=[0.7], scheduler="DDIMScheduler", use_ipadapter=0, dreambooth_path="", lora_model_paths=[str(tree["root"] / "style_lora.safetensors")],
+                 lora_weights=[0.5], motion_module_lora_configs=[], prompt="a cat, easynegative", n_prompt="easynegative, blurry", seed=3,
+                 width=64, height=64, steps=2, strength=1.0, guidance_scale=7.5, frame_count=4, overlaps=0, epoch=0,
+                 output_video_dir="tmp/output", save_frames=0, guess_mode=0, ipa_scale=0.4, use_img2img=0)
+    cfg.update(over)
+    return cfg
+
+
+def test_constructor_builds_everything_from_local_files(model_tree):
+    from controlanimate_amd.controlanimate_pipeline import ControlAnimatePipeline
+    from controlanimate_amd.controlnet import ControlNetModel
+    tree = model_tree
+    pipe = ControlAnimatePipeline(_config(tree))          # <- scripts/vid2vid.py:152
+    p = pipe.pipeline
+    # UNet: 2-D weights loaded, motion module merged, LoRA fused with scale * alpha / rank
+    sd = p.unet.state_dict()
+    k = "down_blocks.0.resnets.0.conv1.weight"
+    assert torch.equal(sd[k], tree["unet_sd"][k])
+    mk = next(iter(tree["mm"]))
+    assert torch.equal(sd[mk], tree["mm"][mk])
+    qk = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight"
+    lo = tree["lora"]
+    want = tree["unet_sd"][qk] + 0.5 * (4.0 / 4) * (lo[f"lora_unet_{tree['q_path']}.lora_up.weight"] @ lo[f"lora_unet_{tree['q_path']}.lora_down.weight"])
+    assert torch.allclose(sd[qk], want, atol=1e-6)
+    # ControlNet stack by name, with the configured scale
+    mc = pipe.multicontrolnetresiduals_pipeline
+    assert len(mc.controlnets) == 1 and isinstance(mc.controlnets[0], ControlNetModel) and mc.cond_scale == [0.7]
+    assert mc.controlnet_names == [str(tree["root"] / "cn-canny")]
+    # scheduler by name with the yaml's kwargs; VAE / text encoder / tokenizer attached
+    assert type(p.scheduler).__name__ == "DDIMScheduler"
+    assert p.vae is not None and p.text_encoder is not None and p.tokenizer is not None
+    # textual inversion: 8 new tokens, their rows in the token table, and the prompts expanded (reference :118-121)
+    assert len(p.tokenizer) == tree["nvocab"] + 8
+    table = p.text_encoder.text_model.embeddings.token_embedding.weight
+    assert table.shape[0] == tree["nvocab"] + 8
+    for i, tok in enumerate(["easynegative"] + [f"easynegative_{j}" for j in range(1, 8)]):
+        assert torch.equal(table[p.tokenizer.convert_tokens_to_ids(tok)], tree["ti"][i])
+    expanded = "easynegative " + " ".join(f"easynegative_{j}" for j in range(1, 8))
+    assert pipe.prompt == "a cat, " + expanded and pipe.n_prompt == expanded + ", blurry"
+    # the surfaces the reference touches on the pipeline object
+    for attr in ("control_image_processor", "load_textual_inversion", "maybe_convert_prompt", "load_lora_weights", "fuse_lora",
+                 "enable_xformers_memory_efficient_attention", "unet", "vae", "text_encoder", "tokenizer", "scheduler", "ip_adapter"):
+        assert hasattr(p, attr), attr
+    if not torch.cuda.is_available():
+        from PIL import Image
+        with pytest.raises(Exception, match="HIP|cuda|GPU|device"):
+            pipe.animate([Image.new("RGB", (64, 64))] * 4, None, _config(tree))
+
+
+def test_missing_model_names_the_places_searched(model_tree):
+    from controlanimate_amd.controlanimate_pipeline import ControlAnimatePipeline
+    with pytest.raises(FileNotFoundError, match="no network"):
+        ControlAnimatePipeline(_config(model_tree, controlnets=["lllyasviel/sd-controlnet-openpose"]))
+
+
+def test_control_image_processor_matches_the_reference_settings():
+    """VaeImageProcessor(do_convert_rgb=True, do_normalize=False) (controlanimation_pipeline.py:160-163): hints in [0,1],
+    sizes rounded down to a multiple of 8."""
+    import numpy as np
+    from PIL import Image
+    from controlanimate_amd.local_models import VaeImageProcessor
+    rng = np.random.default_rng(0)
+    im = Image.fromarray(rng.integers(0, 255, (70, 90, 3), dtype=np.uint8))
+    ctrl = VaeImageProcessor(vae_scale_factor=8, do_convert_rgb=True, do_normalize=False).preprocess(im)
+    assert ctrl.shape == (1, 3, 64, 88) and ctrl.min() >= 0 and ctrl.max() <= 1
+    exact = VaeImageProcessor(do_normalize=False).preprocess(Image.fromarray(np.asarray(im)[:64, :88]))
+    assert torch.equal(exact[0].permute(1, 2, 0), torch.from_numpy(np.asarray(im)[:64, :88].astype(np.float32) / 255.0))
+    norm = VaeImageProcessor().preprocess(im, height=64, width=64)
+    assert norm.shape == (1, 3, 64, 64) and norm.min() >= -1 and norm.min() < 0
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/models/TI/easynegative.safetensors"), reason="reference tree absent")
+def test_the_reference_textual_inversion_file_is_readable():
+    from controlanimate_amd.local_models import read_textual_inversion
+    tokens, emb = read_textual_inversion("/root/reference/models/TI/easynegative.safetensors", token="easynegative")
+    assert tokens == ["easynegative"] + [f"easynegative_{i}" for i in range(1, 8)] and tuple(emb.shape) == (8, 768)

@@ -2,10 +2,12 @@
 sampler kernel) replays the scenarios captured from the REFERENCE's own `__call__` (tests/golden/loop_reference.npz,
 make_loop_golden.py) -- same frames, prompts, seeds, stand-in VAE -- and is compared step by step.
 
-Bounds.  eps = the UNet's raw output of a step (both CFG halves).  Step 0 sees the reference's exact inputs: north-star
-bound 1e-2 (measured ~2e-3).  Later steps also carry the trajectory error: the CFG combine multiplies the independent
-fp16 rounding errors of the two halves by sqrt(g^2 + (g-1)^2) (~10 at g = 7.5, ~1.6 at g = 1.5) per step, so their bound
-is stated per scenario and the x0-prediction of the LCM samplers (what the pipeline decodes) is checked as well."""
+Bounds.  eps = the UNet's raw output of a step (both CFG halves).
+  * EVERY step, teacher-forced (the step is run from the reference's latents of that step: `step_range` hook): the
+    north-star bound 1e-2 on eps (measured ~2e-3); for the noise-free sampler (DDIM) also the latents after that one step.
+  * the free-running trajectory: step 0 sees the reference's exact inputs (1e-2 again); later steps also carry the
+    trajectory error -- the CFG combine multiplies the independent fp16 rounding errors of the two halves by
+    sqrt(g^2 + (g-1)^2) (~10 at g = 7.5, ~1.6 at g = 1.5) per step -- so their bound is stated per scenario."""
 import os
 import sys
 
@@ -32,7 +34,7 @@ def rel(a, b):
 
 
 # scenario -> (eps bound of steps > 0, bound on the latents after the last step)
-BOUNDS = {"custom_lcm": (1e-2, 1e-2), "ddim_cfg": (6e-2, 1.5e-1), "lcm_lora_guess_overlap": (1.5e-2, 1.5e-2), "overlap_no_img2img": (6e-2, 1e-1)}
+BOUNDS = {"custom_lcm": (1e-2, 1e-2), "ddim_cfg": (2e-1, 2e-1), "lcm_lora_guess_overlap": (1.5e-2, 1.5e-2), "overlap_no_img2img": (1e-1, 1e-1)}
 
 
 @pytest.mark.parametrize("name", list(SCENARIOS))
@@ -85,3 +87,19 @@ def test_hip_pipeline_replays_the_reference_call(name):
     assert max(errs) < e_later, errs
     assert lerrs[-1] < l_final, lerrs
     assert rel(out, fx(name, "final")) < l_final   # (native LCM: the x0 prediction `denoised`, which is what gets decoded)
+
+    # ---- every step on the reference's own inputs
+    forced = []
+    for i in range(n):
+        start = fx(name, "init_latents") if i == 0 else fx(name, f"latents{i - 1}")
+        one = []
+        pipe(video_length=sc["frames"], input_frames=frames, height=PX, width=PX, num_inference_steps=sc["steps"], strength=sc["strength"],
+             guidance_scale=sc["guidance"], generator=torch.Generator().manual_seed(0), overlaps=sc["overlaps"],
+             multicontrolnetresiduals_pipeline=cn, prompt_embeds=pos, negative_prompt_embeds=neg, use_lcm=sc["use_lcm"],
+             guess_mode=sc["guess_mode"], use_img2img=sc["use_img2img"], output_type="latent", latents=start, step_range=(i, i + 1),
+             callback=lambda j, t, l: one.append(l.clone()))
+        forced.append(rel(pipe.eps_history[0], fx(name, f"eps{i}")))
+        if sc["scheduler"] == "DDIMScheduler":  # deterministic update: one step from identical inputs
+            assert rel(one[0], fx(name, f"latents{i}")) < 3e-2, (i, rel(one[0], fx(name, f"latents{i}")))
+    print(name, "teacher-forced eps rel_l2 per step:", ["%.2e" % e for e in forced])
+    assert max(forced) < 1e-2, forced
