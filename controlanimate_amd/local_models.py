@@ -221,7 +221,9 @@ def maybe_convert_prompt(prompt, tokenizer):
     `tok tok_1 tok_2 ...` for as long as those exist among the tokenizer's added tokens."""
     if isinstance(prompt, (list, tuple)):
         return [maybe_convert_prompt(p, tokenizer) for p in prompt]
-    added = getattr(tokenizer, "added_tokens_encoder", {})
+    added = getattr(tokenizer, "added_tokens_encoder", None) or {}
+    if not added or not hasattr(tokenizer, "tokenize") or not isinstance(prompt, str):
+        return prompt  # nothing was added to this tokenizer (or it is a caller-supplied callable without a vocabulary)
     seen = []
     for tok in tokenizer.tokenize(prompt):
         if tok in seen or tok not in added:

@@ -221,14 +221,32 @@ def test_non_square_latents_12_frames_two_controlnets_vs_oracle():
     f, h, w = 12, 16, 24
     g = torch.Generator().manual_seed(72)
     sample = torch.randn(1, 4, f, h, w, generator=g)
-    ehs = torch.randn(1, 77, 768, generator=g) * 0.5
+    ehs = torch.cat([torch.randn(1, 77, 768, generator=g) * 0.5, torch.randn(1, 4, 768, generator=g)], dim=1)  # 77 text + 4 image tokens
+    assert ehs.shape[1] == 81
     hints = [torch.rand(f, 3, 8 * h, 8 * w, generator=g) for _ in range(2)]
     scales = [0.7, 1.1]
+    # IP-Adapter processors on the UNet's 16 cross-attention sites (modules/ip_adapter.py:95-127) ...
+    from controlanimate_amd.attention_processor import AttnProcessor2_0, CNAttnProcessor2_0, IPAttnProcessor2_0
+    procs, ip_oracle = {}, {}
+    for name in unet.attn_processors.keys():
+        if "attn2" in name and "temporal_transformer" not in name:
+            hidden = unet.get_submodule(name[: -len(".processor")]).to_q.out_features
+            pr = IPAttnProcessor2_0(hidden_size=hidden, cross_attention_dim=768, scale=0.4, num_tokens=4)
+            pr.to_k_ip.weight.data.copy_(torch.randn(hidden, 768, generator=g) * 768 ** -0.5)
+            pr.to_v_ip.weight.data.copy_(torch.randn(hidden, 768, generator=g) * 768 ** -0.5)
+            procs[name] = pr
+            ip_oracle[name[: -len(".processor")]] = dict(to_k_ip=pr.to_k_ip.weight.data.clone(), to_v_ip=pr.to_v_ip.weight.data.clone(),
+                                                         scale=0.4, num_tokens=4)
+        else:
+            procs[name] = AttnProcessor2_0()
+    unet.set_attn_processor(procs)
+    unet.prepare(DEV, torch.float16)
     nets, cws = [], []
     for i in range(2):
         cw = init_controlnet_weights(ccfg, seed=73 + i)
         net = ControlNetModel.from_config(controlnet_config(block_out_channels=SMALL))
         net.load_state_dict(cw)
+        net.set_attn_processor(CNAttnProcessor2_0(num_tokens=4))  # ... and the token-stripping one on the ControlNets (:129-134)
         nets.append(net.to(DEV).prepare(DEV, torch.float16))
         cws.append(cw)
     # oracle: per-frame ControlNets on the (b f) batch, residuals summed, then the UNet
@@ -236,12 +254,12 @@ def test_non_square_latents_12_frames_two_controlnets_vs_oracle():
         x2d = sample.permute(0, 2, 1, 3, 4).reshape(f, 4, h, w)
         down_sum, mid_sum = None, None
         for cw, hint, sc in zip(cws, hints, scales):
-            d, m = controlnet_forward(cw, ccfg, x2d, 300, ehs.expand(f, -1, -1), hint, conditioning_scale=sc, guess_mode=False)
+            d, m = controlnet_forward(cw, ccfg, x2d, 300, ehs.expand(f, -1, -1), hint, conditioning_scale=sc, guess_mode=False, strip_tokens=4)
             down_sum = list(d) if down_sum is None else [a + b for a, b in zip(down_sum, d)]
             mid_sum = m if mid_sum is None else mid_sum + m
         to5 = lambda t: t.reshape(1, f, *t.shape[1:]).permute(0, 2, 1, 3, 4)
         ref = unet3d_forward(uw, ucfg, sample, 300, ehs, down_block_additional_residuals=[to5(d) for d in down_sum],
-                             mid_block_additional_residual=to5(mid_sum))
+                             mid_block_additional_residual=to5(mid_sum), ip=ip_oracle)
     cn = MultiControlNetResidualsPipeline(["a", "b"], scales, use_lcm=False, controlnets=nets, device=DEV)
     cn.prep_control_images({"a": [x for x in hints[0]], "b": [x for x in hints[1]]}, do_classifier_free_guidance=False, guess_mode=False)
     down, mid = cn(sample.to(DEV), 300, ehs.to(DEV), f, do_classifier_free_guidance=False, guess_mode=False)
