@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcontrolanimate_hip.so")
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class CAHipUnavailable(RuntimeError):
@@ -112,6 +112,7 @@ SYMBOLS = {
     "ca_cfg_scheduler_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_float), C.c_float, C.c_void_p]),
+    "ca_lincomb": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int32, C.c_int64, C.c_void_p]),
 }
 
 _lib = None

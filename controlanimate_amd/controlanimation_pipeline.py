@@ -66,6 +66,8 @@ class ControlAnimationPipeline:
             self.unet.to(self.device)
         if hasattr(self.vae, "to"):
             self.vae.to(self.device)
+        if isinstance(self.text_encoder, torch.nn.Module):
+            self.text_encoder.to(self.device)
         return self
 
     @property
@@ -349,16 +351,21 @@ class ControlAnimationPipeline:
                 eps = model_eps(x, t)
             if self.record_eps:
                 self.eps_history.append(K.nhwc_to_ncfhw_f32(eps, rep, 4, f).cpu())
-            coef, clip = sched.coefficients(idx)
             noise = None
             if sched.needs_noise and len(sched.timesteps) > 1:
-                if isinstance(sched, DiffusersLCMScheduler):
-                    noise = torch.randn(latents.shape, generator=generator, dtype=torch.float32)
-                else:
+                if isinstance(sched, LCMScheduler) and not isinstance(sched, DiffusersLCMScheduler):
                     noise = torch.randn(latents.shape)  # global CPU RNG, as the reference (:1601)
+                else:
+                    noise = torch.randn(latents.shape, generator=generator, dtype=torch.float32)  # randn_tensor with the CPU generator
                 noise = noise.to(device)
-            latents, den = K.cfg_scheduler_step(eps, rep, guidance_scale if rep == 2 else 1.0, latents, noise, coef, clip,
-                                                want_denoised=use_lcm)
+            if getattr(sched, "multistep", False):
+                # history-carrying samplers (DPM-Solver++, LMS, PNDM): CFG combine, then one linear-combination launch
+                e = K.cfg_combined_eps(eps, rep, guidance_scale if rep == 2 else 1.0, latents)
+                latents, den = sched.step_device(idx, e, latents, noise, K.lincomb), None
+            else:
+                coef, clip = sched.coefficients(idx)
+                latents, den = K.cfg_scheduler_step(eps, rep, guidance_scale if rep == 2 else 1.0, latents, noise, coef, clip,
+                                                    want_denoised=use_lcm)
             if use_lcm:
                 denoised = den
             if callback is not None and i % callback_steps == 0:

@@ -139,6 +139,23 @@ __global__ void k_cfg_scheduler_step(const float* eps, int ld_eps, int rep, floa
   if (den_out) den_out[i] = den;
 }
 
+struct LinComb {
+  const float* x[8];
+  float c[8];
+  int n_terms;
+};
+
+__global__ void k_lincomb(float* out, LinComb a, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < a.n_terms) v = fmaf(a.c[k], a.x[k][i], v);
+    out[i] = v;
+  }
+}
+
 inline unsigned blocks_for(int64_t n, int bs, int64_t cap = 1 << 20) {
   int64_t b = (n + bs - 1) / bs;
   if (b > cap) b = cap;
@@ -281,5 +298,21 @@ extern "C" int ca_cfg_scheduler_step(const float* eps, int32_t ld_eps, int32_t r
   const int64_t n = (int64_t)c * f * h * w;
   hipLaunchKernelGGL(k_cfg_scheduler_step, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, eps, ld_eps, rep, guidance, latents, noise, prev, denoised, c, f, h, w, k, clip);
   CA_CHECK_LAUNCH("ca_cfg_scheduler_step");
+  return CA_OK;
+}
+
+extern "C" int ca_lincomb(float* out, const float* const* x, const float* coef, int32_t n_terms, int64_t n, void* stream) {
+  CA_REQUIRE(out && x && coef, "ca_lincomb: null operand");
+  CA_REQUIRE(n_terms >= 1 && n_terms <= 8, "ca_lincomb: n_terms=%d must be 1..8", n_terms);
+  CA_REQUIRE(n > 0, "ca_lincomb: n=%lld", (long long)n);
+  LinComb a{};
+  a.n_terms = n_terms;
+  for (int k = 0; k < n_terms; ++k) {
+    CA_REQUIRE(x[k] != nullptr, "ca_lincomb: x[%d] is null", k);
+    a.x[k] = x[k];
+    a.c[k] = coef[k];
+  }
+  hipLaunchKernelGGL(k_lincomb, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, out, a, n);
+  CA_CHECK_LAUNCH("ca_lincomb");
   return CA_OK;
 }

@@ -339,3 +339,23 @@ def cfg_scheduler_step(eps: torch.Tensor, rep: int, guidance: float, latents: to
                                       _p(noise), prev.data_ptr(), _p(den), c, f, h, w, cf, float(clip), _stream()),
           "ca_cfg_scheduler_step")
     return prev, den
+
+
+def lincomb(terms, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = sum_k coef_k * x_k for fp32 tensors of one shape; terms: [(tensor, coef), ...] (1..8). ca_lincomb."""
+    xs = [t for t, _ in terms]
+    _req_cuda(*xs)
+    assert 1 <= len(terms) <= 8 and all(t.dtype == torch.float32 and t.is_contiguous() and t.shape == xs[0].shape for t in xs)
+    if out is None:
+        out = torch.empty_like(xs[0])
+    ptrs = (C.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+    cf = (C.c_float * len(xs))(*[float(c) for _, c in terms])
+    check(lib().ca_lincomb(out.data_ptr(), ptrs, cf, len(xs), xs[0].numel(), _stream()), "ca_lincomb")
+    return out
+
+
+def cfg_combined_eps(eps: torch.Tensor, rep: int, guidance: float, latents: torch.Tensor) -> torch.Tensor:
+    """The classifier-free-guidance combine alone: eps NHWC fp32 [rep*f,h,w,ld] -> [1,c,f,h,w] fp32
+    (ca_cfg_scheduler_step with prev := eps; the multistep samplers keep it as history)."""
+    e, _ = cfg_scheduler_step(eps, rep, guidance, latents, None, [0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0], 0.0)
+    return e

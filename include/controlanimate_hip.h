@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 4
+#define CA_ABI_VERSION 5
 
 /* element types */
 #define CA_BF16 0
@@ -305,6 +305,14 @@ int ca_cfg_scheduler_step(const float* eps, int32_t ld_eps, int32_t rep, float g
                           const float* latents, const float* noise, float* prev, float* denoised,
                           int32_t c, int32_t f, int32_t h, int32_t w, const float coef[7],
                           float clip, void* stream);
+
+/* out[i] = sum_k coef[k] * x[k][i], fp32, 1 <= n_terms <= 8 (out may alias any x[k]).
+ * The update rule of the MULTISTEP / history-carrying samplers the reference's facade offers
+ * (modules/controlanimate_pipeline.py:52-61: DPMSolverMultistep, LMSDiscrete, PNDM): each of their steps is a fixed
+ * linear combination of the current sample, the current and earlier model outputs and (ancestral) noise, with
+ * host-computed coefficients (controlanimate_amd/schedulers.py).  The CFG combine that precedes it is
+ * ca_cfg_scheduler_step with coef = {0,1,0,0, 0,1,0} (prev := combined eps). */
+int ca_lincomb(float* out, const float* const* x, const float* coef, int32_t n_terms, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,10 @@ def make_scheduler(name: str, kwargs: dict):
         return S.DiffusersLCM(**kwargs)
     if name == "EulerDiscreteScheduler":
         return S.EulerDiscrete(**kwargs)
+    extra = {"EulerAncestralDiscreteScheduler": S.EulerAncestral, "LMSDiscreteScheduler": S.LMSDiscrete,
+             "DPMSolverMultistepScheduler": S.DPMSolverMultistep, "PNDMScheduler": S.PNDM}
+    if name in extra:
+        return extra[name](**kwargs)
     raise NotImplementedError(name)
 
 
@@ -116,7 +120,7 @@ def denoise_loop(unet_sd, unet_cfg: UNet3DConfig, inp: LoopInputs, controlnets: 
                 pu, pc = pred.chunk(2)
                 pred = pu + inp.guidance_scale * (pc - pu)
             eps_hist.append(pred)
-            if isinstance(sched, S.DiffusersLCM):
+            if isinstance(sched, (S.DiffusersLCM, S.EulerAncestral)):
                 latents, _ = sched.step(pred, t, latents, noise=noise)
             else:
                 latents, _ = sched.step(pred, t, latents)

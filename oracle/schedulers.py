@@ -207,3 +207,171 @@ def get_w_embedding(w: torch.Tensor, embedding_dim: int = 512) -> torch.Tensor:
     if embedding_dim % 2 == 1:
         emb = torch.nn.functional.pad(emb, (0, 1))
     return emb
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The remaining samplers of the reference's table (modules/controlanimate_pipeline.py:52-61), restated from
+# diffusers 0.23.0 in the SHAPE of its step functions (tensor arithmetic with history lists), i.e. independently of the
+# coefficient tables of controlanimate_amd/schedulers.py which are tested against these.  Third-party arithmetic:
+# parity unpinned (no diffusers here, no reference test vectors).
+class EulerAncestral(EulerDiscrete):
+    def step(self, model_output, timestep, sample, noise=None, generator=None):
+        i = self._index(timestep)
+        sigma = self.sigmas[i]
+        pred_original = sample - sigma * model_output
+        s_from, s_to = self.sigmas[i], self.sigmas[i + 1]
+        s_up = (s_to ** 2 * (s_from ** 2 - s_to ** 2) / s_from ** 2) ** 0.5
+        s_down = (s_to ** 2 - s_up ** 2) ** 0.5
+        derivative = (sample - pred_original) / sigma
+        prev = sample + derivative * (s_down - sigma)
+        if noise is None:
+            noise = torch.randn(model_output.shape, generator=generator)
+        self._step_index += 1
+        return prev + noise * s_up, pred_original
+
+
+class LMSDiscrete(EulerDiscrete):
+    def set_timesteps(self, num_inference_steps: int):
+        super().set_timesteps(num_inference_steps)
+        self.derivatives = []
+
+    def _coeff(self, order, t, current_order):
+        from scipy import integrate
+        sig = [float(s) for s in self.sigmas]
+
+        def f(tau):
+            prod = 1.0
+            for k in range(order):
+                if current_order == k:
+                    continue
+                prod *= (tau - sig[t - k]) / (sig[t - current_order] - sig[t - k])
+            return prod
+        return integrate.quad(f, sig[t], sig[t + 1], epsrel=1e-4)[0]
+
+    def step(self, model_output, timestep, sample, order: int = 4):
+        i = self._index(timestep)
+        sigma = self.sigmas[i]
+        pred_original = sample - sigma * model_output
+        self.derivatives.append((sample - pred_original) / sigma)
+        if len(self.derivatives) > order:
+            self.derivatives.pop(0)
+        order = min(i + 1, order)
+        coeffs = [self._coeff(order, i, k) for k in range(order)]
+        prev = sample + sum(c * d for c, d in zip(coeffs, reversed(self.derivatives)))
+        self._step_index += 1
+        return prev, pred_original
+
+
+class DPMSolverMultistep(_Base):
+    """dpmsolver++ / order 2 / midpoint / lower_order_final, 'linspace' spacing, sigma formulation."""
+
+    def __init__(self, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", solver_order=2):
+        super().__init__(beta_start, beta_end, beta_schedule)
+        self.solver_order = solver_order
+
+    def set_timesteps(self, num_inference_steps: int):
+        self.num_inference_steps = num_inference_steps
+        ts = np.linspace(0, self.num_train_timesteps - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        sig = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        last = float(((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [last]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts)
+        self.model_outputs = [None] * self.solver_order
+        self.lower_order_nums = 0
+        self._step = 0
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha, sigma * alpha
+
+    def step(self, model_output, timestep, sample):
+        i = self._step
+        lower_final = i == len(self.timesteps) - 1 and len(self.timesteps) < 15
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[i])
+        x0 = (sample - sigma_t * model_output) / alpha_t
+        for k in range(self.solver_order - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+        self.model_outputs[-1] = x0
+        a_t, s_t = self._alpha_sigma(self.sigmas[i + 1])
+        a_s0, s_s0 = self._alpha_sigma(self.sigmas[i])
+        lam_t, lam_s0 = torch.log(a_t) - torch.log(s_t), torch.log(a_s0) - torch.log(s_s0)
+        h = lam_t - lam_s0
+        if self.solver_order == 1 or self.lower_order_nums < 1 or lower_final:
+            prev = (s_t / s_s0) * sample - (a_t * (torch.exp(-h) - 1.0)) * x0
+        else:
+            a_s1, s_s1 = self._alpha_sigma(self.sigmas[i - 1])
+            lam_s1 = torch.log(a_s1) - torch.log(s_s1)
+            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+            r0 = (lam_s0 - lam_s1) / h
+            d0, d1 = m0, (1.0 / r0) * (m0 - m1)
+            prev = (s_t / s_s0) * sample - (a_t * (torch.exp(-h) - 1.0)) * d0 - 0.5 * (a_t * (torch.exp(-h) - 1.0)) * d1
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        self._step += 1
+        return prev, x0
+
+
+class PNDM(_Base):
+    """skip_prk_steps=False, set_alpha_to_one=False, 'leading' spacing, steps_offset 0 (diffusers' defaults)."""
+
+    def __init__(self, beta_start=0.00085, beta_end=0.012, beta_schedule="linear"):
+        super().__init__(beta_start, beta_end, beta_schedule)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self.pndm_order = 4
+
+    def set_timesteps(self, num_inference_steps: int):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self._timesteps = (np.arange(0, num_inference_steps) * ratio).round()
+        prk = np.array(self._timesteps[-self.pndm_order:]).repeat(2) + np.tile(
+            np.array([0, self.num_train_timesteps // num_inference_steps // 2]), self.pndm_order)
+        self.prk_timesteps = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+        self.plms_timesteps = self._timesteps[:-3][::-1].copy()
+        self.timesteps = torch.from_numpy(np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64))
+        self.ets, self.counter, self.cur_model_output, self.cur_sample = [], 0, 0, None
+
+    def _prev(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        sample_coeff = (a_prev / a_t) ** 0.5
+        denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
+        return sample_coeff * sample - (a_prev - a_t) * model_output / denom
+
+    def step(self, model_output, timestep, sample):
+        timestep = int(timestep)
+        ratio = self.num_train_timesteps // self.num_inference_steps
+        if self.counter < len(self.prk_timesteps):
+            diff = 0 if self.counter % 2 else ratio // 2
+            prev_timestep = timestep - diff
+            timestep = int(self.prk_timesteps[self.counter // 4 * 4])
+            if self.counter % 4 == 0:
+                self.cur_model_output = self.cur_model_output + 1 / 6 * model_output
+                self.ets.append(model_output)
+                self.cur_sample = sample
+            elif (self.counter - 1) % 4 == 0:
+                self.cur_model_output = self.cur_model_output + 1 / 3 * model_output
+            elif (self.counter - 2) % 4 == 0:
+                self.cur_model_output = self.cur_model_output + 1 / 3 * model_output
+            elif (self.counter - 3) % 4 == 0:
+                model_output = self.cur_model_output + 1 / 6 * model_output
+                self.cur_model_output = 0
+            prev = self._prev(self.cur_sample, timestep, prev_timestep, model_output)
+        else:
+            prev_timestep = timestep - ratio
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+            e = self.ets
+            if len(e) == 1:
+                m = e[-1]
+            elif len(e) == 2:
+                m = (3 * e[-1] - e[-2]) / 2
+            elif len(e) == 3:
+                m = (23 * e[-1] - 16 * e[-2] + 5 * e[-3]) / 12
+            else:
+                m = (1 / 24) * (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4])
+            prev = self._prev(sample, timestep, prev_timestep, m)
+        self.counter += 1
+        return prev, None

@@ -105,6 +105,10 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu(capi):
     expect(lib.ca_attention(C.byref(capi.AttnArgs(q=fake, k=fake, v=fake, o=fake, head_dim=40, batches=1, heads=1, nq=4, nk=8, inner_count=1,
                                                  kv_inner_count=1, kv_div=1, q_row=40, k_row=40, o_row=40, dtype=1, causal=1)), None), "ca_attention")  # causal nq != nk
     expect(lib.ca_softmax_rows(fake, fake, 4, 10, 12, 12, 1.0, 1, None), "ca_softmax_rows")                       # cols % 4
+    ptrs, cf = (C.c_void_p * 2)(0x1000, 0x2000), (C.c_float * 2)(1.0, 2.0)
+    expect(lib.ca_lincomb(fake, ptrs, cf, 9, 64, None), "ca_lincomb")                                              # > 8 terms
+    expect(lib.ca_lincomb(fake, ptrs, cf, 2, 0, None), "ca_lincomb")                                               # n = 0
+    expect(lib.ca_lincomb(None, ptrs, cf, 2, 64, None), "ca_lincomb")
 
 
 def test_no_cpu_fallback_when_library_missing(monkeypatch):

@@ -156,3 +156,61 @@ def test_window_plan_and_blend():
     assert torch.allclose(out[:, 0, 0], torch.tensor([3.5, 2.5, 1.5, 0.5]) / 4)  # Image.blend alpha (n-i-0.5)/n
     with pytest.raises(ValueError):
         window_plan(10, 8, 8)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The four samplers added in round 2 (EulerAncestral, LMS, DPM-Solver++ multistep, PNDM): the product's host-computed
+# coefficient tables (one fused / one lincomb launch per step) against the step-function-shaped oracle restatements.
+def _torch_lincomb(terms):
+    out = torch.zeros_like(terms[0][0])
+    for x, c in terms:
+        out = out + float(c) * x
+    return out
+
+
+@pytest.mark.parametrize("name,oracle_cls,steps", [("EulerAncestralDiscreteScheduler", "EulerAncestral", 7), ("LMSDiscreteScheduler", "LMSDiscrete", 9),
+                                                   ("DPMSolverMultistepScheduler", "DPMSolverMultistep", 8), ("DPMSolverMultistepScheduler", "DPMSolverMultistep", 20),
+                                                   ("PNDMScheduler", "PNDM", 6), ("PNDMScheduler", "PNDM", 20)])
+def test_round2_schedulers_match_their_oracle(name, oracle_cls, steps):
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+    from controlanimate_amd.schedulers import get_scheduler
+    from oracle import schedulers as OS
+    prod = get_scheduler(name, **NOISE_SCHEDULER_KWARGS)
+    prod.set_timesteps(steps)
+    ora = getattr(OS, oracle_cls)(**NOISE_SCHEDULER_KWARGS)
+    ora.set_timesteps(steps)
+    assert [round(float(t), 3) for t in prod.timesteps] == [round(float(t), 3) for t in ora.timesteps]
+    if name == "PNDMScheduler":
+        assert len(prod.timesteps) == 12 + steps - 3      # 3 Runge-Kutta steps of 4 evaluations, then the multistep part
+    g = torch.Generator().manual_seed(steps)
+    shape = (1, 4, 3, 5, 5)
+    xp = xo = torch.randn(shape, generator=g, dtype=torch.float64) * float(getattr(prod, "init_noise_sigma", 1.0))
+    for i, t in enumerate(prod.timesteps):
+        eps = torch.randn(shape, generator=g, dtype=torch.float64)
+        noise = torch.randn(shape, generator=g, dtype=torch.float64)
+        assert abs(prod.input_scale(i) - float((ora.scale_model_input(torch.ones(1, dtype=torch.float64), ora.timesteps[i]))[0])) < 1e-6
+        if getattr(prod, "multistep", False):
+            xp = prod.step_device(i, eps, xp, noise, _torch_lincomb)
+            xo = ora.step(eps, ora.timesteps[i], xo)[0]
+        else:
+            c, clip = prod.coefficients(i)
+            x0 = (xp - c[0] * eps) * c[1]
+            den = c[2] * x0 + c[3] * xp
+            xp = c[4] * den + c[5] * eps + c[6] * noise
+            xo = ora.step(eps, ora.timesteps[i], xo, noise=noise)[0]
+        rel = float((xp - xo).norm() / xo.norm())
+        assert rel < 2e-5, (name, i, rel)
+    assert torch.isfinite(xp).all()
+
+
+def test_every_scheduler_of_the_reference_table_is_selectable():
+    """modules/controlanimate_pipeline.py:52-61."""
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+    from controlanimate_amd.schedulers import get_scheduler
+    for n in ("EulerDiscreteScheduler", "DDIMScheduler", "DPMSolverMultistepScheduler", "EulerAncestralDiscreteScheduler",
+              "LMSDiscreteScheduler", "PNDMScheduler", "LCMScheduler"):
+        s = get_scheduler(n, **NOISE_SCHEDULER_KWARGS)
+        s.set_timesteps(10)
+        assert len(s.timesteps) >= 10
+    with pytest.raises(NotImplementedError):
+        get_scheduler("UniPCMultistepScheduler")

@@ -499,3 +499,21 @@ def test_layout_kernels_and_scheduler_step():
     pref = coef[4] * dref + coef[5] * e + coef[6] * noise
     assert torch.allclose(den.cpu(), dref, atol=1e-5, rtol=1e-5)
     assert torch.allclose(prev.cpu(), pref, atol=1e-5, rtol=1e-5)
+
+
+def test_lincomb_and_cfg_combined_eps():
+    """ca_lincomb (update rule of the history-carrying samplers) and the CFG combine alone."""
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(1, 4, 5, 6, 7, generator=g).to(DEV) for _ in range(5)]
+    cs = [0.7, -1.3, 2.5, 1e-3, -0.25]
+    out = K.lincomb(list(zip(xs, cs)))
+    ref = sum(c * x.double() for x, c in zip(xs, cs))
+    assert torch.allclose(out.double(), ref, atol=1e-5)
+    inplace = K.lincomb([(xs[0], 2.0), (xs[1], 1.0)], out=xs[0].clone())
+    assert torch.allclose(inplace, 2.0 * xs[0] + xs[1], atol=1e-6)
+    f, h, w = 5, 6, 7
+    eps = torch.randn(2 * f, h, w, 4, generator=g).to(DEV)
+    lat = torch.randn(1, 4, f, h, w, generator=g).to(DEV)
+    e = K.cfg_combined_eps(eps, 2, 7.5, lat)
+    eu, ec = eps[:f].permute(3, 0, 1, 2)[None], eps[f:].permute(3, 0, 1, 2)[None]
+    assert torch.allclose(e, eu + 7.5 * (ec - eu), atol=1e-5)

@@ -84,11 +84,15 @@ def run_both(ucfg, uw, unet, ccfg, cws, nets, *, scheduler, steps, guidance, str
         so.set_timesteps(strength, steps, 50)
         init = so.add_noise(input_latents, init, so.timesteps[:1])
         noises = [torch.randn(init.shape) for _ in so.timesteps]           # global RNG draws, in order
-    elif scheduler == "LCMScheduler":
+    elif scheduler in ("LCMScheduler", "EulerAncestralDiscreteScheduler"):
         noises = [torch.randn(init.shape, generator=gen) for _ in range(steps)]
+        if scheduler == "EulerAncestralDiscreteScheduler":
+            e = OS.EulerAncestral(**NOISE_SCHEDULER_KWARGS)
+            e.set_timesteps(steps)
+            init = init * e.init_noise_sigma
     else:
         noises = None
-        if scheduler == "EulerDiscreteScheduler":
+        if scheduler in ("EulerDiscreteScheduler", "LMSDiscreteScheduler"):
             e = OS.EulerDiscrete(**NOISE_SCHEDULER_KWARGS)
             e.set_timesteps(steps)
             init = init * e.init_noise_sigma
@@ -165,3 +169,14 @@ def test_cfg_controlnet_prompt_tiling_quirk_euler():
     out, ref, errs = run_both(*parts, scheduler="EulerDiscreteScheduler", steps=4, guidance=3.0, cond_scale=[1.0])
     print("per-step latent rel_l2:", ["%.2e" % e for e in errs])
     assert errs[0] < 1e-2 and errs[-1] < 4e-2, errs
+
+
+@pytest.mark.parametrize("scheduler,steps", [("DPMSolverMultistepScheduler", 4), ("LMSDiscreteScheduler", 5), ("PNDMScheduler", 4),
+                                             ("EulerAncestralDiscreteScheduler", 4)])
+def test_remaining_schedulers_of_the_reference_table(scheduler, steps):
+    """The four samplers of modules/controlanimate_pipeline.py:52-61 beyond DDIM / LCM / Euler, through the HIP loop
+    (CFG combine kernel + ca_lincomb for the history-carrying ones) against the oracle loop; guidance 1.5."""
+    parts = build("v2", seed=27)
+    out, ref, errs = run_both(*parts, scheduler=scheduler, steps=steps, guidance=1.5)
+    print(scheduler, "per-step latent rel_l2:", ["%.2e" % e for e in errs])
+    assert len(errs) == len(ref["latents"]) and errs[0] < 1e-2 and max(errs) < 3e-2, errs
