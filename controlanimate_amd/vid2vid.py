@@ -6,8 +6,12 @@ Per window (file:line of the reference behaviour mirrored):
   :168-175  batch = the previous window's last `overlap_length` INPUT frames + (frame_count - overlaps) new ones
   :189-192  with overlaps: strength := overlap_strength; loop_back_frames feeds the previous OUTPUT frames back in
   :197-213  optional initial IP-Adapter round (run once, then re-run on its own last frames)
-  :215-221  colour match every frame to `last_output_frame` (third-party color_matcher 'hm-mkl-hm' in the
-            reference; here a callable hook, default = per-channel mean/std transfer, see match_colors_meanstd)
+  :215-221  colour match every frame to `last_output_frame` (the reference calls the third-party color_matcher package
+            with method 'hm-mkl-hm', modules/utils.py:116-130; `match_colors` below restates that compound:
+            histogram matching -> Monge-Kantorovich linear transfer -> histogram matching)
+  :93-136   raw-RGB frames through ffmpeg pipes (FFMPEGProcessor, modules/utils.py:87-113) -- `FFMPEGProcessor`,
+            `ffmpeg_reader_cmd`, `ffmpeg_writer_cmd` below; `prefetch` decodes the next windows' frames on a host thread
+            while the GPU denoises the current one (the reference reads synchronously)
   :221      last_output_frame = frames[overlap_length - 1]   (index -1, the last frame, when overlap_length == 0)
   :223-224  last_output_frames = frames[-overlap_length:]     (IP-Adapter image prompt / latent init of the next window)
   :226-228  cross-fade: frames[i] = blend(frames[i], previous_overlap_output[i], (n - i - 0.5) / n)
@@ -51,9 +55,7 @@ def blend(a, b, alpha: float):
 
 
 def match_colors_meanstd(frames: Sequence, ref_frame) -> List:
-    """Default colour-match hook: per-channel mean/std transfer to `ref_frame` (Reinhard).  The reference
-    calls the third-party color_matcher package ('hm-mkl-hm', modules/utils.py:116-130), which is absent
-    here; pass that as `match_colors=` to reproduce it exactly."""
+    """Cheap alternative hook: per-channel mean/std transfer to `ref_frame` (Reinhard).  The default is `match_colors`."""
     ref = _to_np(ref_frame).astype(np.float32)
     rm, rs = ref.reshape(-1, ref.shape[-1]).mean(0), ref.reshape(-1, ref.shape[-1]).std(0) + 1e-6
     out = []
@@ -63,6 +65,122 @@ def match_colors_meanstd(frames: Sequence, ref_frame) -> List:
         y = (x - m) / s * rs + rm
         out.append(_like(np.clip(y + 0.5, 0, 255).astype(np.uint8), fr))
     return out
+
+
+def _hist_match(src: np.ndarray, ref: np.ndarray) -> np.ndarray:
+    """Per-channel histogram matching (color_matcher `hm`): every source value is sent to the reference value of equal
+    cumulative frequency (quantile mapping with linear interpolation).  float arrays [H,W,C]."""
+    out = np.empty_like(src, dtype=np.float64)
+    for c in range(src.shape[-1]):
+        s, r = src[..., c].ravel(), ref[..., c].ravel()
+        s_val, s_idx, s_cnt = np.unique(s, return_inverse=True, return_counts=True)
+        r_val, r_cnt = np.unique(r, return_counts=True)
+        s_q = np.cumsum(s_cnt).astype(np.float64) / s.size
+        r_q = np.cumsum(r_cnt).astype(np.float64) / r.size
+        out[..., c] = np.interp(s_q, r_q, r_val)[s_idx].reshape(src.shape[:-1])
+    return out
+
+
+def _mkl(src: np.ndarray, ref: np.ndarray) -> np.ndarray:
+    """Monge-Kantorovich linear colour transfer (Pitie & Kokaram 2007; color_matcher `mkl`): the linear map that carries
+    the source colour covariance onto the reference's, T = Cs^-1/2 (Cs^1/2 Cr Cs^1/2)^1/2 Cs^-1/2, about the means."""
+    x = src.reshape(-1, src.shape[-1]).astype(np.float64)
+    y = ref.reshape(-1, ref.shape[-1]).astype(np.float64)
+    mx, my = x.mean(0), y.mean(0)
+    cs, cr = np.cov(x, rowvar=False), np.cov(y, rowvar=False)
+    eps = np.finfo(np.float64).eps
+
+    def sqrtm(a):
+        w, v = np.linalg.eigh(a)
+        return (v * np.sqrt(np.clip(w, eps, None))) @ v.T
+
+    cs_h = sqrtm(cs)
+    cs_hi = np.linalg.inv(cs_h)
+    t = cs_hi @ sqrtm(cs_h @ cr @ cs_h) @ cs_hi
+    return ((x - mx) @ t + my).reshape(src.shape)
+
+
+def match_colors(frames: Sequence, ref_frame) -> List:
+    """modules/utils.py:116-130: every frame is colour-matched to `ref_frame` with the compound 'hm-mkl-hm'
+    (histogram matching, then the Monge-Kantorovich linear transfer, then histogram matching again) on [0,1] floats,
+    and written back as uint8.  The reference delegates to the `color_matcher` package (absent here: this restatement
+    is unpinned against it; the property tests are in tests/test_vid2vid_host.py)."""
+    ref = _to_np(ref_frame).astype(np.float64) / 255.0
+    out = []
+    for fr in frames:
+        x = _to_np(fr).astype(np.float64) / 255.0
+        y = _hist_match(_mkl(_hist_match(x, ref), ref), ref)
+        out.append(_like(np.clip(np.round(y * 255.0), 0, 255).astype(np.uint8), fr))
+    return out
+
+
+class FFMPEGProcessor:
+    """modules/utils.py:87-113: a child process whose stdin / stdout carries raw frames.  `read(count)` returns a uint8
+    array of up to `count` bytes, `write(array)` sends its bytes, `close()` ends the input."""
+
+    def __init__(self, cmd, std_in: bool = False, std_out: bool = False):
+        from subprocess import PIPE, Popen
+        self.process = Popen(cmd, stdin=PIPE if std_in else None, stdout=PIPE if std_out else None, shell=isinstance(cmd, str))
+
+    def read(self, count: int) -> np.ndarray:
+        return np.frombuffer(self.process.stdout.read(count), dtype=np.uint8)
+
+    def write(self, in_array) -> None:
+        self.process.stdin.write(np.ascontiguousarray(in_array).tobytes())
+
+    def close(self) -> int:
+        if self.process.stdin is not None:
+            self.process.stdin.close()
+        return self.process.wait()
+
+
+def ffmpeg_reader_cmd(path: str, width: int, height: int, fps: float, start_time: str = "00:00:00", end_time: Optional[str] = None) -> str:
+    """The decoder command of scripts/vid2vid.py:93-106: scaled raw rgb24 frames on stdout."""
+    to = f" -to {end_time}" if end_time else ""
+    return (f'ffmpeg -loglevel error -ss {start_time}{to} -i "{path}" -vf "fps={fps},scale={width}:{height}" '
+            f"-f rawvideo -pix_fmt rgb24 -")
+
+
+def ffmpeg_writer_cmd(path: str, width: int, height: int, fps: float, crf: int = 17) -> str:
+    """The encoder command of scripts/vid2vid.py:120-136: raw rgb24 frames on stdin -> h264."""
+    return (f"ffmpeg -loglevel error -y -f rawvideo -pix_fmt rgb24 -s {width}x{height} -r {fps} -i - "
+            f'-c:v libx264 -pix_fmt yuv420p -crf {crf} "{path}"')
+
+
+def frames_from_pipe(reader: FFMPEGProcessor, width: int, height: int) -> Iterator:
+    """Raw rgb24 stream -> PIL frames (vid2vid.py:143-147,170-174: `read(width*height*3)` per frame until EOF)."""
+    n = width * height * 3
+    while True:
+        buf = reader.read(n)
+        if buf.size < n:
+            return
+        yield _like(buf.reshape(height, width, 3).copy(), None if Image is None else Image)
+
+
+def prefetch(frames: Iterable, depth: int = 32) -> Iterator:
+    """Decodes ahead on a host thread: the next windows' input frames are read (ffmpeg pipe, disk) while the GPU works
+    on the current window.  Order-preserving; exceptions of the producer are re-raised in the consumer."""
+    import queue
+    import threading
+    q: "queue.Queue" = queue.Queue(maxsize=depth)
+    end = object()
+
+    def work():
+        try:
+            for fr in frames:
+                q.put(fr)
+            q.put(end)
+        except BaseException as exc:  # noqa: BLE001
+            q.put(exc)
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is end:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
 
 
 @dataclass
@@ -86,7 +204,7 @@ AnimateFn = Callable[[List, Optional[List], WindowConfig], List]
 
 
 def run_windows(input_frames: Optional[Iterable], animate: AnimateFn, cfg: WindowConfig, total_frames: Optional[int] = None,
-                match_colors: Optional[Callable[[Sequence, object], List]] = match_colors_meanstd) -> Iterator[List]:
+                match_colors: Optional[Callable[[Sequence, object], List]] = match_colors) -> Iterator[List]:
     """Yields the output frames of each window, in order (what the reference writes to the encoder).
     input_frames: iterable of frames (vid2vid) or None (text-to-video: `total_frames` must be given and the
     batches are lists of None of the window length).  `animate(batch, last_output_frames, cfg)` is

@@ -10,7 +10,7 @@ import torch
 import yaml
 from safetensors.torch import save_file
 
-BOC = (32, 64, 128, 128)
+BOC = (64, 128, 256, 256)   # head dims 8 / 16 / 32 / 32 (the attention kernel takes multiples of 8)
 
 
 def _write_tokenizer(d):
@@ -79,7 +79,7 @@ def model_tree(tmp_path, monkeypatch):
     yaml.safe_dump(dict(unet_additional_kwargs=dict(INFERENCE_V2), noise_scheduler_kwargs=dict(NOISE_SCHEDULER_KWARGS)),
                    open(root / "inference-v2.yaml", "w"))
     q = "down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q"
-    lora = {f"lora_unet_{q}.lora_down.weight": torch.randn(4, 32) * 0.1, f"lora_unet_{q}.lora_up.weight": torch.randn(32, 4) * 0.1,
+    lora = {f"lora_unet_{q}.lora_down.weight": torch.randn(4, BOC[0]) * 0.1, f"lora_unet_{q}.lora_up.weight": torch.randn(BOC[0], 4) * 0.1,
             f"lora_unet_{q}.alpha": torch.tensor(4.0)}
     save_file(lora, str(root / "style_lora.safetensors"))
     os.makedirs(root / "models" / "TI")

@@ -503,6 +503,7 @@ def test_layout_kernels_and_scheduler_step():
 
 def test_lincomb_and_cfg_combined_eps():
     """ca_lincomb (update rule of the history-carrying samplers) and the CFG combine alone."""
+    from controlanimate_amd import kernels as K
     g = torch.Generator().manual_seed(3)
     xs = [torch.randn(1, 4, 5, 6, 7, generator=g).to(DEV) for _ in range(5)]
     cs = [0.7, -1.3, 2.5, 1e-3, -0.25]

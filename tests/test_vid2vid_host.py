@@ -96,3 +96,53 @@ def test_meanstd_match_moves_statistics():
     src = rng.normal(150, 30, (16, 16, 3)).clip(0, 255).astype(np.uint8)
     out = np.asarray(match_colors_meanstd([src], ref)[0]).astype(np.float32)
     assert abs(out.mean() - ref.mean()) < 1.5 and abs(out.std() - ref.std()) < 1.5
+
+
+def test_match_colors_hm_mkl_hm_properties():
+    """The 'hm-mkl-hm' compound of modules/utils.py:116-130 (restated; the color_matcher package is absent)."""
+    import numpy as np
+    from controlanimate_amd.vid2vid import _hist_match, _mkl, match_colors
+    rng = np.random.default_rng(0)
+    ref = np.clip(rng.normal([150, 90, 60], [30, 20, 10], (48, 64, 3)), 0, 255).astype(np.uint8)
+    src = np.clip(rng.normal([80, 120, 200], [15, 35, 25], (48, 64, 3)), 0, 255).astype(np.uint8)
+    out = match_colors([src], ref)[0]
+    assert out.dtype == np.uint8 and out.shape == src.shape
+    # marginal statistics of every channel move onto the reference's (the final step is a histogram match)
+    for c in range(3):
+        assert abs(out[..., c].mean() - ref[..., c].mean()) < 1.5 and abs(out[..., c].std() - ref[..., c].std()) < 1.5
+        assert np.abs(np.sort(out[..., c].ravel()).astype(float) - np.sort(ref[..., c].ravel())).mean() < 1.0
+    # matching an image to itself changes nothing (up to one grey level of float round-off); MKL maps the covariance exactly
+    assert np.abs(match_colors([ref], ref)[0].astype(int) - ref.astype(int)).max() <= 1
+    x, y = src.astype(np.float64) / 255, ref.astype(np.float64) / 255
+    t = _mkl(x, y).reshape(-1, 3)
+    assert np.allclose(np.cov(t, rowvar=False), np.cov(y.reshape(-1, 3), rowvar=False), atol=1e-8)
+    assert np.allclose(t.mean(0), y.reshape(-1, 3).mean(0), atol=1e-10)
+    # histogram matching is monotone per channel: the rank order of the pixels is preserved
+    h = _hist_match(x, y)
+    i, j = rng.integers(0, x[..., 0].size, 200), rng.integers(0, x[..., 0].size, 200)
+    a, b = x[..., 0].ravel(), h[..., 0].ravel()
+    assert np.all((a[i] < a[j]) <= (b[i] <= b[j]))
+
+
+def test_ffmpeg_pipe_class_and_prefetch():
+    """FFMPEGProcessor (modules/utils.py:87-113) with `cat` standing for ffmpeg, frames_from_pipe and the async prefetcher."""
+    import numpy as np
+    from controlanimate_amd.vid2vid import FFMPEGProcessor, ffmpeg_reader_cmd, ffmpeg_writer_cmd, frames_from_pipe, prefetch
+    w, h, n = 8, 6, 5
+    rng = np.random.default_rng(1)
+    frames = [rng.integers(0, 255, (h, w, 3), dtype=np.uint8) for _ in range(n)]
+    proc = FFMPEGProcessor("cat", std_in=True, std_out=True)
+    for f in frames:
+        proc.write(f)
+    proc.process.stdin.close()
+    got = list(prefetch(frames_from_pipe(proc, w, h), depth=2))
+    assert proc.process.wait() == 0
+    assert len(got) == n and all(np.array_equal(np.asarray(a), b) for a, b in zip(got, frames))
+    assert "rawvideo" in ffmpeg_reader_cmd("in.mp4", 512, 512, 15) and "-s 512x512" in ffmpeg_writer_cmd("out.mp4", 512, 512, 15)
+
+    def boom():
+        yield 1
+        raise ValueError("decoder died")
+    import pytest
+    with pytest.raises(ValueError, match="decoder died"):
+        list(prefetch(boom()))
