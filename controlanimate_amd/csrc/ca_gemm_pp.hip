@@ -26,6 +26,32 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
     const unsigned c_bytes = (unsigned)((((int64_t)p.m - 1) * p.ldc + ncols) * 2);
     const unsigned res_bytes = p.res ? (unsigned)((((int64_t)p.m - 1) * p.ld_res + p.n) * 2) : 0u;
     const unsigned grid = tiles < (unsigned)cu_count() ? tiles : (unsigned)cu_count();
+    if (p.dbg == 9) {  // timing experiment: shader-clock stamps of block 0 (see ca_gemm_pp3.h), printed to stderr
+      static unsigned long long* dbuf = nullptr;
+      if (!dbuf && hipMalloc(&dbuf, 4096 * 8) != hipSuccess) return CA_ERR_LAUNCH;
+      (void)hipMemsetAsync(dbuf, 0, 4096 * 8, st);
+      GemmKParams q = p;
+      q.partial = reinterpret_cast<float*>(dbuf);
+      hipLaunchKernelGGL((k_gemm_pp3<DT, MODE>), dim3(grid), dim3(512), 0, st, q, (int)tiles, c_bytes, res_bytes);
+      (void)hipStreamSynchronize(st);
+      static int printed = 0;
+      if (printed++ < 1) {
+        static unsigned long long host[4096];
+        (void)hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost);
+        for (int g = 0; g < 2; ++g) {
+          fprintf(stderr, "[pp3 stamps group %d] tag:delta_cycles ...\n", g);
+          unsigned long long prev = host[g * 2048];
+          for (int i = 0; i < 1000 && host[g * 2048 + 2 * i]; ++i) {
+            fprintf(stderr, "%llu:%llu ", host[g * 2048 + 2 * i + 1], host[g * 2048 + 2 * i] - prev);
+            prev = host[g * 2048 + 2 * i];
+            if (host[g * 2048 + 2 * i + 1] == 12) fprintf(stderr, "| ");
+            if (host[g * 2048 + 2 * i + 1] == 14) fprintf(stderr, "\n");
+          }
+          fprintf(stderr, "\n");
+        }
+      }
+      return CA_OK;
+    }
     hipLaunchKernelGGL((k_gemm_pp3<DT, MODE>), dim3(grid), dim3(512), 0, st, p, (int)tiles, c_bytes, res_bytes);
     return CA_OK;
   }

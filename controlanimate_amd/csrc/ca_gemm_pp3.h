@@ -22,30 +22,134 @@
 // multiple of 64 rows, operands addressable with 32-bit byte offsets.
 
 __device__ __forceinline__ void ca_vm_wait(int n) {
-  // Waits until at most n VMEM operations of this wave are outstanding (rounded DOWN to the next value of the table:
-  // a smaller count is a safe over-wait).  One asm statement with its own scalar branches: written as C++ `if` chains
-  // or a `switch` hipcc structurises the (wave-uniform!) control flow into ~40 SALU instructions and a dozen taken
-  // branches per call, which made the whole K loop run at a third of its speed.
+  // Waits until at most n VMEM operations of this wave are outstanding: EXACT for 0 <= n <= 23 (larger: 23, a safe
+  // over-wait).  The steady-state value is tested first; the rest is a balanced decision tree of scalar compares written
+  // as ONE asm statement (5 compares deep): as C++ `if` chains or a `switch` hipcc structurises the (wave-uniform!) control
+  // flow into ~40 SALU instructions per call, and a table that rounds n DOWN makes the wave wait for pieces issued only one
+  // phase earlier, which stalls it for the rest of their latency (both measured with s_memtime stamps).
+  if (n == 7) {
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    return;
+  }
+  n = __builtin_amdgcn_readfirstlane(n > 23 ? 23 : (n < 0 ? 0 : n));  // (an SGPR for the asm operand)
   asm volatile(
-      "s_cmp_ge_i32 %0, 16\n\ts_cbranch_scc1 16f\n\t"
-      "s_cmp_ge_i32 %0, 13\n\ts_cbranch_scc1 13f\n\t"
-      "s_cmp_ge_i32 %0, 10\n\ts_cbranch_scc1 10f\n\t"
-      "s_cmp_ge_i32 %0, 9\n\ts_cbranch_scc1 9f\n\t"
-      "s_cmp_ge_i32 %0, 8\n\ts_cbranch_scc1 8f\n\t"
-      "s_cmp_ge_i32 %0, 7\n\ts_cbranch_scc1 7f\n\t"
-      "s_cmp_ge_i32 %0, 6\n\ts_cbranch_scc1 6f\n\t"
-      "s_cmp_ge_i32 %0, 4\n\ts_cbranch_scc1 4f\n\t"
-      "s_cmp_ge_i32 %0, 3\n\ts_cbranch_scc1 3f\n\t"
-      "s_waitcnt vmcnt(0)\n\ts_branch 99f\n"
-      "16:\ts_waitcnt vmcnt(16)\n\ts_branch 99f\n"
-      "13:\ts_waitcnt vmcnt(13)\n\ts_branch 99f\n"
-      "10:\ts_waitcnt vmcnt(10)\n\ts_branch 99f\n"
-      "9:\ts_waitcnt vmcnt(9)\n\ts_branch 99f\n"
-      "8:\ts_waitcnt vmcnt(8)\n\ts_branch 99f\n"
-      "7:\ts_waitcnt vmcnt(7)\n\ts_branch 99f\n"
-      "6:\ts_waitcnt vmcnt(6)\n\ts_branch 99f\n"
-      "4:\ts_waitcnt vmcnt(4)\n\ts_branch 99f\n"
-      "3:\ts_waitcnt vmcnt(3)\n"
+      "s_cmp_ge_i32 %0, 12\n\t"
+      "s_cbranch_scc1 30f\n\t"
+      "s_cmp_ge_i32 %0, 6\n\t"
+      "s_cbranch_scc1 31f\n\t"
+      "s_cmp_ge_i32 %0, 3\n\t"
+      "s_cbranch_scc1 32f\n\t"
+      "s_cmp_ge_i32 %0, 1\n\t"
+      "s_cbranch_scc1 33f\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_branch 99f\n\t"
+      "33:\n"
+      "s_cmp_ge_i32 %0, 2\n\t"
+      "s_cbranch_scc1 34f\n\t"
+      "s_waitcnt vmcnt(1)\n\t"
+      "s_branch 99f\n\t"
+      "34:\n"
+      "s_waitcnt vmcnt(2)\n\t"
+      "s_branch 99f\n\t"
+      "32:\n"
+      "s_cmp_ge_i32 %0, 4\n\t"
+      "s_cbranch_scc1 35f\n\t"
+      "s_waitcnt vmcnt(3)\n\t"
+      "s_branch 99f\n\t"
+      "35:\n"
+      "s_cmp_ge_i32 %0, 5\n\t"
+      "s_cbranch_scc1 36f\n\t"
+      "s_waitcnt vmcnt(4)\n\t"
+      "s_branch 99f\n\t"
+      "36:\n"
+      "s_waitcnt vmcnt(5)\n\t"
+      "s_branch 99f\n\t"
+      "31:\n"
+      "s_cmp_ge_i32 %0, 9\n\t"
+      "s_cbranch_scc1 37f\n\t"
+      "s_cmp_ge_i32 %0, 7\n\t"
+      "s_cbranch_scc1 38f\n\t"
+      "s_waitcnt vmcnt(6)\n\t"
+      "s_branch 99f\n\t"
+      "38:\n"
+      "s_cmp_ge_i32 %0, 8\n\t"
+      "s_cbranch_scc1 39f\n\t"
+      "s_waitcnt vmcnt(7)\n\t"
+      "s_branch 99f\n\t"
+      "39:\n"
+      "s_waitcnt vmcnt(8)\n\t"
+      "s_branch 99f\n\t"
+      "37:\n"
+      "s_cmp_ge_i32 %0, 10\n\t"
+      "s_cbranch_scc1 40f\n\t"
+      "s_waitcnt vmcnt(9)\n\t"
+      "s_branch 99f\n\t"
+      "40:\n"
+      "s_cmp_ge_i32 %0, 11\n\t"
+      "s_cbranch_scc1 41f\n\t"
+      "s_waitcnt vmcnt(10)\n\t"
+      "s_branch 99f\n\t"
+      "41:\n"
+      "s_waitcnt vmcnt(11)\n\t"
+      "s_branch 99f\n\t"
+      "30:\n"
+      "s_cmp_ge_i32 %0, 18\n\t"
+      "s_cbranch_scc1 42f\n\t"
+      "s_cmp_ge_i32 %0, 15\n\t"
+      "s_cbranch_scc1 43f\n\t"
+      "s_cmp_ge_i32 %0, 13\n\t"
+      "s_cbranch_scc1 44f\n\t"
+      "s_waitcnt vmcnt(12)\n\t"
+      "s_branch 99f\n\t"
+      "44:\n"
+      "s_cmp_ge_i32 %0, 14\n\t"
+      "s_cbranch_scc1 45f\n\t"
+      "s_waitcnt vmcnt(13)\n\t"
+      "s_branch 99f\n\t"
+      "45:\n"
+      "s_waitcnt vmcnt(14)\n\t"
+      "s_branch 99f\n\t"
+      "43:\n"
+      "s_cmp_ge_i32 %0, 16\n\t"
+      "s_cbranch_scc1 46f\n\t"
+      "s_waitcnt vmcnt(15)\n\t"
+      "s_branch 99f\n\t"
+      "46:\n"
+      "s_cmp_ge_i32 %0, 17\n\t"
+      "s_cbranch_scc1 47f\n\t"
+      "s_waitcnt vmcnt(16)\n\t"
+      "s_branch 99f\n\t"
+      "47:\n"
+      "s_waitcnt vmcnt(17)\n\t"
+      "s_branch 99f\n\t"
+      "42:\n"
+      "s_cmp_ge_i32 %0, 21\n\t"
+      "s_cbranch_scc1 48f\n\t"
+      "s_cmp_ge_i32 %0, 19\n\t"
+      "s_cbranch_scc1 49f\n\t"
+      "s_waitcnt vmcnt(18)\n\t"
+      "s_branch 99f\n\t"
+      "49:\n"
+      "s_cmp_ge_i32 %0, 20\n\t"
+      "s_cbranch_scc1 50f\n\t"
+      "s_waitcnt vmcnt(19)\n\t"
+      "s_branch 99f\n\t"
+      "50:\n"
+      "s_waitcnt vmcnt(20)\n\t"
+      "s_branch 99f\n\t"
+      "48:\n"
+      "s_cmp_ge_i32 %0, 22\n\t"
+      "s_cbranch_scc1 51f\n\t"
+      "s_waitcnt vmcnt(21)\n\t"
+      "s_branch 99f\n\t"
+      "51:\n"
+      "s_cmp_ge_i32 %0, 23\n\t"
+      "s_cbranch_scc1 52f\n\t"
+      "s_waitcnt vmcnt(22)\n\t"
+      "s_branch 99f\n\t"
+      "52:\n"
+      "s_waitcnt vmcnt(23)\n\t"
+      "s_branch 99f\n\t"
       "99:\n"
       :
       : "s"(n)
@@ -63,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp3(GemmKParams p, int tiles_to
   constexpr int PAR_BASE = 2 * BUF * 2;
   constexpr int P_CS = 0, P_BI = 2048, P_RB0 = 4096, P_RB1 = 6144, P_ST = 8192, PSET = 9216;
   constexpr int STG_BASE = PAR_BASE + 2 * PSET;
-  constexpr int STG_ROW = 176, STG_WAVE = 3072;  // per wave: 16 rows x (160 B + 16 B pad) of staged values, or 3 x 1 KB residual pieces
+  constexpr int STG_WAVE = 3072;  // per wave: the residual of one 16-row slice as 3 LDS-DMA pieces of 1 KB
   constexpr int SMEM_BYTES = STG_BASE + 8 * STG_WAVE;
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[SMEM_BYTES];
   u16* const smem = reinterpret_cast<u16*>(smem_b);
@@ -92,6 +196,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp3(GemmKParams p, int tiles_to
   const __amdgpu_buffer_rsrc_t rs_rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.rowbias ? (const void*)p.rowbias : (const void*)p.w), 0,
                                                                          p.rowbias ? (unsigned)(((int64_t)(rb_groups - 1) * p.ld_rowbias + p.n) * 4) : 0u, 0x00020000);
 
+  // timing experiment (CA_PP_DBG=9): block 0, waves 0 and 4 (one of each group) stamp the shader clock into p.partial
+  unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(p.partial);
+  int stamp_i = 0;
+  auto stamp = [&](int tag) __attribute__((always_inline)) {
+#ifndef CA_PP3_STAMPS
+    (void)tag;
+    return;
+#endif
+    if (p.dbg == 9 && blockIdx.x == 0 && (wid == 0 || wid == 4) && lane == 0 && stamp_i < 1000) {
+      stamps[(wid >> 2) * 2048 + 2 * stamp_i] = __builtin_readcyclecounter();
+      stamps[(wid >> 2) * 2048 + 2 * stamp_i + 1] = (unsigned long long)tag;
+      ++stamp_i;
+    }
+  };
   auto swz = [](int row) { return (row >> 1) & 7; };
   const int r8 = lane >> 3, cp = lane & 7;
   const int kc = p.c1 + p.c2;
@@ -269,6 +387,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp3(GemmKParams p, int tiles_to
   // residual of slice d of the pending tile -> this wave's LDS patch, by LDS-DMA (no VGPR destination: the compiler
   // neither sees nor waits for these loads).  Piece u, lane l = chunk (l & 3) + 4u of row l >> 2: the store mapping.
   auto drain_prefetch = [&](int d) __attribute__((always_inline)) {
+    if (!p.res) return;
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));  // (no hoisting of the address arithmetic: see dma_set_tile)
     const int dr_row = lane_o >> 2, dr_c0 = lane_o & 3;
@@ -276,65 +395,71 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp3(GemmKParams p, int tiles_to
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const bool ok = (u < 2 || dr_c0 < 2) && m < p.m;
-      const unsigned off = ok ? (unsigned)(((int64_t)m * p.ld_res + pend_n0 + wc * 80 + (dr_c0 + 4 * u) * 8) * 2) : OOB_V;
+      const unsigned off = ok ? (unsigned)m * (unsigned)p.ld_res * 2u + (unsigned)(pend_n0 + wc * 80 + (dr_c0 + 4 * u) * 8) * 2u : OOB_V;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (__attribute__((address_space(3))) void*)(stg + u * 1024), 16, off, 0, 0, 0);
     }
     issued += 3;
     mark_res = issued;
   };
-  auto drain_store = [&](auto dc) __attribute__((always_inline)) {  // slice d: pend -> LDS patch -> 16-byte chunks (+ residual, post, act, GEGLU) -> global
+  auto drain_store = [&](auto dc) __attribute__((always_inline)) {
+    // slice d (16 rows of this wave's patch): the 5 packed fragments go to global IN FRAGMENT LAYOUT -- a lane holds 4
+    // consecutive columns of one row, one 8-byte store per fragment (16 rows x 32 B per instruction; the four
+    // instructions that complete a 128-byte line follow each other, the L2 merges them).  No LDS transposition: with
+    // it a slice cost ~2900 cycles of LDS round trips in the load segment while the partner group idled at the barrier
+    // (measured with s_memtime stamps: 11 us per tile).  The residual comes from the wave's LDS patch (LDS-DMA a slice
+    // ahead), read back in the same fragment layout.
     constexpr int d = decltype(dc)::value;
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));
-    const int dr_row = lane_o >> 2, dr_c0 = lane_o & 3, l15 = lane_o & 15, g = lane_o >> 4;
-    ca_vm_wait(issued - mark_res);  // this wave's residual pieces have landed (wave-private patch: no barrier)
-    u32x4 rv[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) rv[u] = ld16(stg + u * 1024 + lane_o * 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staged values overwrite the residual pieces
-    __builtin_amdgcn_sched_barrier(0);
+    const int l15 = lane_o & 15, g = lane_o >> 4;
+    const int m = pend_m0 + wr * 64 + d * 16 + l15;
+    const bool ok = m < p.m && p.dbg != 1;
+    if (p.res) ca_vm_wait(issued - mark_res);  // this wave's residual pieces have landed (wave-private patch: no barrier)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      u32x2 v = {pend[d][j][0], pend[d][j][1]};
-      *reinterpret_cast<u32x2*>(stg + l15 * STG_ROW + (j * 16 + g * 4) * 2) = v;
-    }
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      u32x4 cvu = ld16(stg + dr_row * STG_ROW + ((dr_c0 + 4 * u) % 10) * 16);
-      __builtin_amdgcn_sched_barrier(0);  // one chunk at a time: keeps the temporaries of this block small
-      const int m = pend_m0 + wr * 64 + d * 16 + dr_row;
-      const bool ok = (u < 2 || dr_c0 < 2) && m < p.m && p.dbg != 1;
-      float v[8];
-      unpack8<DT>(cvu, v);
+      __builtin_amdgcn_sched_barrier(0);  // one fragment at a time: keeps the temporaries of this block small
+      u32x2 rvj = {0u, 0u};
       if (p.res) {
-        float r[8];
-        unpack8<DT>(rv[u], r);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += r[k];
+        const int ch = 2 * j + (g >> 1);  // 8-column chunk of the row; piece = ch / 4, lane of the piece = row * 4 + ch % 4
+        rvj = *reinterpret_cast<const u32x2*>(stg + (ch >> 2) * 1024 + (l15 * 4 + (ch & 3)) * 16 + (g & 1) * 8);
+      }
+      // (the empty asm keeps hipcc from hoisting the fp16 -> fp32 unpacking of all 80 pending values out of the K loop:
+      //  loop-invariant code motion did exactly that and the 80 extra live registers spilled)
+      unsigned p0 = pend[d][j][0], p1 = pend[d][j][1];
+      asm volatile("" : "+v"(p0), "+v"(p1));
+      float v[4];
+      v[0] = Elem<DT>::to_f((u16)(p0 & 0xffffu));
+      v[1] = Elem<DT>::to_f((u16)(p0 >> 16));
+      v[2] = Elem<DT>::to_f((u16)(p1 & 0xffffu));
+      v[3] = Elem<DT>::to_f((u16)(p1 >> 16));
+      if (p.res) {
+        v[0] += Elem<DT>::to_f((u16)(rvj[0] & 0xffffu));
+        v[1] += Elem<DT>::to_f((u16)(rvj[0] >> 16));
+        v[2] += Elem<DT>::to_f((u16)(rvj[1] & 0xffffu));
+        v[3] += Elem<DT>::to_f((u16)(rvj[1] >> 16));
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] *= p.post;
+      for (int k = 0; k < 4; ++k) v[k] *= p.post;
       if (p.act != CA_ACT_NONE) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = act_f(v[k], p.act);
+        for (int k = 0; k < 4; ++k) v[k] = act_f(v[k], p.act);
       }
-      const int ncol = pend_n0 + wc * 80 + (dr_c0 + 4 * u) * 8;
+      const int ncol = pend_n0 + wc * 80 + j * 16 + g * 4;
+      if (p.dbg == 7 || (p.dbg == 8 && j > 0)) continue;  // (experiment knobs: no store instruction / one per slice)
       if (p.geglu) {
-        float o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = v[2 * k] * gelu_erf_f(v[2 * k + 1]);
-        u32x2 w;
-        w[0] = pack2<DT>(o[0], o[1]);
-        w[1] = pack2<DT>(o[2], o[3]);
-        const unsigned off = ok ? (unsigned)(((int64_t)m * p.ldc + (ncol >> 1)) * 2) : OOB_V;
-        __builtin_amdgcn_raw_buffer_store_b64(w, rs_c, off, 0, 0);
+        const unsigned w = pack2<DT>(v[0] * gelu_erf_f(v[1]), v[2] * gelu_erf_f(v[3]));
+        const unsigned off = ok ? (unsigned)m * (unsigned)p.ldc * 2u + (unsigned)(ncol >> 1) * 2u : OOB_V;
+        __builtin_amdgcn_raw_buffer_store_b32(w, rs_c, off, 0, 0);
       } else {
-        const unsigned off = ok ? (unsigned)(((int64_t)m * p.ldc + ncol) * 2) : OOB_V;
-        __builtin_amdgcn_raw_buffer_store_b128(pack8<DT>(v), rs_c, off, 0, 0);
+        u32x2 w;
+        w[0] = pack2<DT>(v[0], v[1]);
+        w[1] = pack2<DT>(v[2], v[3]);
+        const unsigned off = ok ? (unsigned)m * (unsigned)p.ldc * 2u + (unsigned)ncol * 2u : OOB_V;
+        __builtin_amdgcn_raw_buffer_store_b64(w, rs_c, off, 0, 0);
       }
     }
-    issued += 3;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the patch is re-filled by the next prefetch)
+    issued += TN;
+    if (p.res) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the patch is re-filled by the next prefetch)
   };
 
   auto mfma_p1 = [&]() __attribute__((always_inline)) {
@@ -380,6 +505,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp3(GemmKParams p, int tiles_to
   {                                                                                                  \
     const int par = cv & 1;                                                                          \
     const u16* buf = smem + par * BUF;                                                               \
+    stamp(1);                                                                                        \
     if (have_pend && t == dnext_t) { /* slice `dnext` of the previous tile */                        \
       if (dnext == 0) {                                                                              \
         drain_store(std::integral_constant<int, 0>{});                                               \
@@ -394,7 +520,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp3(GemmKParams p, int tiles_to
         drain_store(std::integral_constant<int, 3>{});                                               \
       }                                                                                              \
       ++dnext;                                                                                       \
-      dnext_t = dnext < 4 ? (dnext * nt) >> 2 : -1;                                                  \
+      dnext_t = dnext < 4 ? ((dnext * nt) >> 2) + dstagger : -1;                                     \
+      stamp(2);                                                                                      \
     }                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                  \
@@ -404,10 +531,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp3(GemmKParams p, int tiles_to
     issue_b1(par ^ 1);                                                                               \
     if (par) mark_b10 = issued; else mark_b11 = issued;                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+    stamp(3);                                                                                        \
     ca_vm_wait(issued - (par ? mark_b11 : mark_b10)); /* B1 of this K tile (read in phase 2) */       \
+    stamp(4);                                                                                        \
     __builtin_amdgcn_s_barrier();                                                                    \
+    stamp(5);                                                                                        \
     mfma_p1();                                                                                       \
+    stamp(6);                                                                                        \
     __builtin_amdgcn_s_barrier();                                                                    \
+    stamp(7);                                                                                        \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                    \
       _Pragma("unroll") for (int j = 0; j < 3; ++j) fb1[j][s] = ld16(buf + fb1_base[s] + j * 16 * KT); \
     if (d_t == nt) { /* the stream enters the next tile */                                           \
@@ -418,10 +550,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp3(GemmKParams p, int tiles_to
     issue_ab0(par);                                                                                  \
     if (par) mark_ab1 = issued; else mark_ab0 = issued;                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+    stamp(8);                                                                                        \
     ca_vm_wait(issued - (par ? mark_ab0 : mark_ab1)); /* A/B0 of the next K tile (read next phase) */ \
+    stamp(9);                                                                                        \
     __builtin_amdgcn_s_barrier();                                                                    \
+    stamp(10);                                                                                       \
     mfma_p2();                                                                                       \
+    stamp(11);                                                                                       \
     __builtin_amdgcn_s_barrier();                                                                    \
+    stamp(12);                                                                                       \
     ++cv;                                                                                            \
   }
 
@@ -475,13 +612,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp3(GemmKParams p, int tiles_to
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
 
+  // blocks drain their slices at different K tiles (offset 0 .. nt/4-1 by block): the stores of the whole chip are spread
+  // in time instead of arriving as one burst per quarter tile
+  const int dstagger = p.dbg == 5 ? 0 : bslot % (nt / 4 > 0 ? nt / 4 : 1);
   int cv = 0;
   for (int seq = 0;; ++seq) {
     if (!tile_of(seq, tm, tn)) break;
     const int m0 = tm * BM, n0 = tn * BN;
-    int dnext = 0, dnext_t = 0;
+    int dnext = 0, dnext_t = dstagger;
     for (int t = 0; t < nt; ++t) CA_PP3_KTILE()
+    stamp(13);
     if (p.dbg != 4) convert(seq, m0);
+    stamp(14);
     have_pend = p.dbg != 3;
     pend_m0 = m0;
     pend_n0 = n0;
