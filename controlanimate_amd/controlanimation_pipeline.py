@@ -49,10 +49,12 @@ class ControlAnimationPipeline:
         if scheduler is None:  # native LCM (reference :95-101)
             scheduler = LCMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", prediction_type="epsilon")
         self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
-        self.vae_scale_factor = 8
+        vcfg = getattr(vae, "config", None)
+        boc = vcfg.get("block_out_channels") if isinstance(vcfg, dict) else getattr(vcfg, "block_out_channels", None)
+        self.vae_scale_factor = 2 ** (len(boc) - 1) if boc else 8  # reference :158 (SD1.5: 8)
         self.ip_adapter = None
         from .local_models import VaeImageProcessor  # reference :159-163
-        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True)
         self.control_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True, do_normalize=False)
         self._pending_lora: List[dict] = []
         self.device = torch.device("cuda")

@@ -452,6 +452,14 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   // tiles: the 16x16- and 32x32-latent levels, +10..19%); with many rounds the exposed epilogue of a one-block-per-CU
   // kernel (35..45% of a K = 1280 GEMM) loses against 4 co-resident blocks of k_gemm_dma.
   static const int pp_env = getenv("CA_GEMM_PP") ? atoi(getenv("CA_GEMM_PP")) : -1;
+  // Weight-resident streaming kernel (ca_gemm_wres.h) for the K = 320 GEMMs of the 64x64-latent level.
+  // CA_GEMM_WRES: unset = on when M >= 16384 (measured: a tie at 32768 rows, ahead above), 0 = never, 1 = whenever the shape qualifies.
+  static const int wres_env = getenv("CA_GEMM_WRES") ? atoi(getenv("CA_GEMM_WRES")) : -1;
+  if (MODE == 0 && dma && wres_env != 0 && kc == 320 && p.taps == 1 && (p.c2 == 0 || p.c1 % 32 == 0) && p.n % 160 == 0 && p.n / 160 <= 32 &&
+      !p.out_f32 && p.splits <= 1 && p.a_bytes < 0x7FFFFF00u && (!p.c2 || p.a2_bytes < 0x7FFFFF00u) && (!p.rowbias || p.rows_per_group % 32 == 0) &&
+      (((int64_t)p.m - 1) * p.ldc + (p.geglu ? p.n / 2 : p.n)) * 2 < 0x7FFFFF00ll && (!p.res || (((int64_t)p.m - 1) * p.ld_res + p.n) * 2 < 0x7FFFFF00ll) &&
+      (wres_env == 1 || p.m >= 16384))
+    return ca_launch_gemm_pp(p, DT, MODE, 160, 0u, st);
   if (dma && pp_env != 0 && pp_env != 3 && nt >= 2 && p.n % 320 == 0 && p.splits <= 1) {  // 128 x 320 tiles
     const int64_t tiles = (int64_t)ceil_div_i(p.m, 128) * (p.n / 320);
     const int64_t ncols = p.geglu ? p.n / 2 : p.n;

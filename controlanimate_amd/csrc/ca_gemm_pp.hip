@@ -7,6 +7,7 @@ using namespace ca_gemm_detail;
 #include "ca_gemm_pp.h"
 #include "ca_gemm_pp2.h"
 #include "ca_gemm_pp3.h"
+#include "ca_gemm_wres.h"
 
 int cu_count() {
   static int n = 0;
@@ -53,6 +54,19 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
       return CA_OK;
     }
     hipLaunchKernelGGL((k_gemm_pp3<DT, MODE>), dim3(grid), dim3(512), 0, st, p, (int)tiles, c_bytes, res_bytes);
+    return CA_OK;
+  }
+  if (bn == 160) {  // weight-resident streaming kernel (K = 320, dense only)
+    if (MODE != 0) return CA_ERR_LAUNCH;
+    const int panels = p.n / 160;
+    const int chunks = (p.m + 255) / 256;
+    int per = (cu_count() / 8) / panels;  // slab lanes per XCD
+    if (per * 8 > chunks) per = chunks / 8;
+    if (per < 1) per = 1;
+    const unsigned rb_bytes = p.rowbias ? (unsigned)(((int64_t)((p.m - 1) / p.rows_per_group) * p.ld_rowbias + p.n) * 4) : 16u;
+    const unsigned c_bytes = (unsigned)((((int64_t)p.m - 1) * p.ldc + (p.geglu ? p.n / 2 : p.n)) * 2);
+    const unsigned res_bytes = p.res ? (unsigned)((((int64_t)p.m - 1) * p.ld_res + p.n) * 2) : 0u;
+    hipLaunchKernelGGL((k_gemm_wres<DT>), dim3(8 * per * panels), dim3(512), 0, st, p, panels, 8 * per, chunks, rb_bytes, c_bytes, res_bytes);
     return CA_OK;
   }
   if (bn == 320) hipLaunchKernelGGL((k_gemm_pp2<DT, MODE>), dim3(tiles), dim3(512), 0, st, p);

@@ -1,0 +1,267 @@
+// Weight-resident streaming GEMM for the K = 320 layers of the 64x64-latent level (q|k|v, out-projections, GEGLU
+// projection, proj_in / proj_out: M = 131072 rows per step and up).  These launches sat off both roofs with the tiled
+// kernels (131072x320x320: 13 % of the MFMA peak at < 40 % of the HBM rate): a block tile lives for five K tiles, each
+// a dependent LDS-DMA round trip, and more than half of the bytes a tile pulls from L2 are the SAME 100 KB of weights.
+//
+//   * a persistent block keeps its 160-column panel of W (160 x 320, 100 KB, rows padded to 656 B: conflict-free
+//     fragment reads) in LDS for its whole life -- loaded once, one barrier, none afterwards;
+//   * each of the 8 waves streams its OWN 32-row slabs of A through a wave-private ring of three 2 KB slots
+//     (32 rows x 32 K per slot, LDS-DMA, counted vmcnt): no barrier anywhere in the stream, a wave's epilogue
+//     (stores, residual reads) overlaps the other waves' MFMAs the way independent blocks would;
+//   * per slab a wave computes 32 x 160 outputs (2 x 10 MFMA tiles, 80 accumulator registers) and writes them from
+//     the accumulator layout (a lane holds 4 consecutive columns of one row: 8-byte stores, 32 B per row and
+//     instruction, ten instructions complete 320 contiguous bytes of each of 16 rows).
+//
+// Work split: block b runs on XCD b % 8; the blocks of an XCD that share a slab sequence ("lane") differ only in their
+// column panel, so a slab is read from HBM once and from that XCD's L2 by the other panels.
+//     slot = b / 8, panel = slot % panels, lane = b % 8 + 8 * (slot / panels); slab chunks (256 rows) lane, lane + lanes, ...
+//
+// Epilogue arithmetic and rounding order are those of gemm_epilogue (ca_gemm_core.h): round((acc [LN fold] + bias +
+// rowbias) * alpha), then + residual, * post, activation, GEGLU, round.
+template <int DT>
+__global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels, int lanes, int chunks, unsigned rb_bytes, unsigned c_bytes, unsigned res_bytes) {
+  constexpr int K = 320, PN = 160, TN = 10, KQ = 10;  // panel width, n tiles per wave, ring chunks (32 K) per slab
+  constexpr int WLD_B = 656;                          // bytes per padded W row (41 16-byte chunks)
+  constexpr int W_BYTES = PN * WLD_B;                 // 104960
+  constexpr int SLOT = 2048, RING = 3 * SLOT;
+  constexpr int OFF_PAR = W_BYTES + 8 * RING;  // bias[160] | colsum[160] (fp32), loaded once with the weights
+  constexpr int OFF_RB = OFF_PAR + 1280;       // per wave: the 160 rowbias values of the current slab's row group (1 KB)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_RB + 8 * 1024];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int slot_b = blockIdx.x >> 3;
+  const int panel = slot_b % panels;
+  const int my_lane = (blockIdx.x & 7) + 8 * (slot_b / panels);
+  if (my_lane >= lanes) return;
+  const int n0 = panel * PN;
+
+  // ---- the weight panel: once
+  for (int q = tid; q < PN * (K / 8); q += 512) {
+    const int row = q / (K / 8), c = q - row * (K / 8);
+    *reinterpret_cast<u32x4*>(smem + row * WLD_B + c * 16) = ld16(p.w + (int64_t)(n0 + row) * K + c * 8);
+  }
+  if (tid < 2 * PN) {
+    const float* src = tid < PN ? p.bias : p.ln_colsum;
+    const int n = tid < PN ? tid : tid - PN;
+    reinterpret_cast<float*>(smem + OFF_PAR)[tid] = src ? src[n0 + n] : 0.f;
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rs_rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.rowbias ? (const void*)p.rowbias : (const void*)p.w), 0, rb_bytes, 0x00020000);
+  unsigned char* rb_patch = smem + OFF_RB + wid * 1024;
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.c), 0, p.res ? res_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, p.a2 ? p.a2_bytes : p.a_bytes, 0x00020000);
+  unsigned char* ring = smem + W_BYTES + wid * RING;
+
+  // ---- stream head (what the next DMA pair fetches): slab chunk d_c, ring chunk d_k of it, slot d_s
+  int d_c = my_lane, d_k = 0, d_s = 0;
+  unsigned d_v1[2], d_v2[2];
+  auto head_slab = [&]() {
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));  // (keeps the address arithmetic where it is used: see ca_gemm_pp3.h)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = d_c * 256 + wid * 32 + h * 16 + (lane_o >> 2);
+      const bool ok = m < p.m;
+      d_v1[h] = ok ? (unsigned)m * (unsigned)p.lda * 2u + (unsigned)(lane_o & 3) * 16u : DMA_OOB;
+      d_v2[h] = ok ? (unsigned)m * (unsigned)p.lda2 * 2u + (unsigned)(lane_o & 3) * 16u : DMA_OOB;
+    }
+  };
+  auto issue = [&]() {  // one ring chunk = 2 DMA instructions (16 rows x 64 B each)
+    const int k0 = d_k * 32;
+    unsigned char* dst = ring + d_s * SLOT;
+    if (k0 >= p.c1) {
+      const unsigned so = (unsigned)(k0 - p.c1) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (__attribute__((address_space(3))) void*)dst, 16, d_v2[0], so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (__attribute__((address_space(3))) void*)(dst + 1024), 16, d_v2[1], so, 0, 0);
+    } else {
+      const unsigned so = (unsigned)k0 * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)dst, 16, d_v1[0], so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + 1024), 16, d_v1[1], so, 0, 0);
+    }
+    d_s = d_s == 2 ? 0 : d_s + 1;
+    if (++d_k == KQ) {
+      d_k = 0;
+      d_c += lanes;  // (past the last chunk every row is out of range: the DMA writes zeros nobody reads)
+      head_slab();
+    }
+  };
+
+  head_slab();
+  issue();
+  issue();
+
+  const int fa_lane = l15 * 64 + g * 16;                    // A fragment: row l15 (+16), 16 bytes at k = g*8
+  const unsigned char* wb = smem + l15 * WLD_B + g * 16;    // W fragment of n tile j, chunk kq: + j*16*WLD_B + kq*64
+  int r_s = 0;                                              // ring slot of the chunk computed next
+
+  for (int c = my_lane; c < chunks; c += lanes) {
+    const int m0 = c * 256 + wid * 32;
+    f32x4 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // LayerNorm statistics of this lane's two rows, and the row group's bias (one group per 32-row slab: the
+    // launcher requires rows_per_group % 32 == 0) by LDS-DMA into the wave's patch -- both long landed at the epilogue
+    float2 st[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    if (p.ln_stats) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + l15;
+        if (m < p.m) st[i] = *reinterpret_cast<const float2*>(p.ln_stats + (int64_t)m * 2);
+      }
+    }
+    if (p.rowbias) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const unsigned off = (lane_o < PN / 4 && m0 < p.m) ? ((unsigned)(m0 / p.rows_per_group) * (unsigned)p.ld_rowbias + (unsigned)n0) * 4u + (unsigned)lane_o * 16u : DMA_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rb, (__attribute__((address_space(3))) void*)rb_patch, 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+      issue();  // two chunks ahead, into the slot whose fragments were consumed in the previous iteration
+      // younger than the chunk computed now: 2 chunks = 4 loads.  Loads return in order among themselves, but stores
+      // retire OUT of order with respect to loads (measured: counting the 20 stores of the previous slab's epilogue as
+      // "younger, may stay outstanding" -- vmcnt(24) at kq == 0 -- gave wrong results): "at most 4 outstanding" also
+      // waits for all but the youngest of those stores, which is conservative, never wrong.
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      const unsigned char* as = ring + r_s * SLOT + fa_lane;
+      // all twelve fragments of the chunk are requested at once; LDS returns them in order, so MFMA pair j starts as
+      // soon as fragment j is in (counted lgkmcnt) while the rest stream in behind it
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 fa0 = *reinterpret_cast<const u32x4*>(as);
+      const u32x4 fa1 = *reinterpret_cast<const u32x4*>(as + 1024);
+      u32x4 fb[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        __builtin_amdgcn_sched_barrier(0);  // (in this order: the waits below count on it)
+        fb[j] = *reinterpret_cast<const u32x4*>(wb + j * 16 * WLD_B + kq * 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#define CA_WRES_PAIR(J, CNT)                                        \
+  asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");         \
+  __builtin_amdgcn_sched_barrier(0);                                \
+  acc[0][J] = Elem<DT>::mfma(fb[J], fa0, acc[0][J]);                \
+  acc[1][J] = Elem<DT>::mfma(fb[J], fa1, acc[1][J]);                \
+  __builtin_amdgcn_sched_barrier(0);
+      CA_WRES_PAIR(0, 9) CA_WRES_PAIR(1, 8) CA_WRES_PAIR(2, 7) CA_WRES_PAIR(3, 6) CA_WRES_PAIR(4, 5)
+      CA_WRES_PAIR(5, 4) CA_WRES_PAIR(6, 3) CA_WRES_PAIR(7, 2) CA_WRES_PAIR(8, 1) CA_WRES_PAIR(9, 0)
+#undef CA_WRES_PAIR
+      // (lgkmcnt(0) above: every read of the slot has returned before the next issue() re-fills it)
+      r_s = r_s == 2 ? 0 : r_s + 1;
+    }
+
+    // ---- epilogue of this wave's 32 x 160 patch, from the accumulators.  Every load is issued before the first
+    // store (the VMEM counter is shared and in order: a load issued after a store could only be awaited together
+    // with that store's completion): residual quads up front, LayerNorm statistics before the K loop, bias / column
+    // sums / row bias from LDS.
+    if (p.dbg == 1) {
+      if (acc[0][0][0] == 12345.678f) *reinterpret_cast<float*>(p.c) = acc[1][TN - 1][1];
+      continue;
+    }
+    u32x2 rr[2][TN];
+    if (p.res) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int m = m0 + i * 16 + l15;
+          const unsigned off = m < p.m ? ((unsigned)m * (unsigned)p.ld_res + (unsigned)(n0 + g * 4)) * 2u : DMA_OOB;  // (out of range reads 0)
+          rr[i][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, j * 32, 0));
+        }
+    }
+    if (!p.ln_stats && !p.rowbias && p.alpha == 1.f && p.post == 1.f && p.act == CA_ACT_NONE && !p.geglu) {
+      // the common case (projections with bias and residual): ~12 VALU instructions per fragment instead of ~45 --
+      // the epilogue's VALU time is of the order of the slab's MFMA time, and it is the part that does not scale away
+      unsigned off[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + l15;
+        off[i] = m < p.m ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(n0 + g * 4)) * 2u : DMA_OOB;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (j * 16 + g * 4) * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          u32x2 w;
+          w[0] = pack2<DT>(acc[i][j][0] + bi[0], acc[i][j][1] + bi[1]);
+          w[1] = pack2<DT>(acc[i][j][2] + bi[2], acc[i][j][3] + bi[3]);
+          if (p.res) {
+            if (DT == CA_F16) {  // fp16 + fp16 is exact in fp32, so the packed add rounds exactly like the fp32 path
+              // (inline asm: hipcc 7.2 miscompiled the ext_vector _Float16 addition here -- the second add reused the
+              //  first one's result and operand)
+              unsigned s0, s1;
+              asm("v_pk_add_f16 %0, %1, %2" : "=v"(s0) : "v"(w[0]), "v"(rr[i][j][0]));
+              asm("v_pk_add_f16 %0, %1, %2" : "=v"(s1) : "v"(w[1]), "v"(rr[i][j][1]));
+              w[0] = s0;
+              w[1] = s1;
+            } else {
+              w[0] = pack2<DT>(Elem<DT>::to_f((u16)(w[0] & 0xffffu)) + Elem<DT>::to_f((u16)(rr[i][j][0] & 0xffffu)),
+                               Elem<DT>::to_f((u16)(w[0] >> 16)) + Elem<DT>::to_f((u16)(rr[i][j][0] >> 16)));
+              w[1] = pack2<DT>(Elem<DT>::to_f((u16)(w[1] & 0xffffu)) + Elem<DT>::to_f((u16)(rr[i][j][1] & 0xffffu)),
+                               Elem<DT>::to_f((u16)(w[1] >> 16)) + Elem<DT>::to_f((u16)(rr[i][j][1] >> 16)));
+            }
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(w, rs_c, off[i], j * 32, 0);
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = j * 16 + g * 4;
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + nl * 4);
+      f32x4 cs = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+      if (p.ln_stats) cs = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (PN + nl) * 4);
+      if (p.rowbias) rb = *reinterpret_cast<const f32x4*>(rb_patch + nl * 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + l15;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if (p.ln_stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = st[i].y * (v[r] - st[i].x * cs[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = Elem<DT>::to_f(Elem<DT>::from_f((v[r] + bi[r] + rb[r]) * p.alpha));
+        if (p.res) {
+          v[0] += Elem<DT>::to_f((u16)(rr[i][j][0] & 0xffffu));
+          v[1] += Elem<DT>::to_f((u16)(rr[i][j][0] >> 16));
+          v[2] += Elem<DT>::to_f((u16)(rr[i][j][1] & 0xffffu));
+          v[3] += Elem<DT>::to_f((u16)(rr[i][j][1] >> 16));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= p.post;
+        if (p.act != CA_ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], p.act);
+        }
+        // (rows past M: the offset is out of the descriptor's range, the hardware drops the store)
+        if (p.geglu) {
+          const unsigned w = pack2<DT>(v[0] * gelu_erf_f(v[1]), v[2] * gelu_erf_f(v[3]));
+          const unsigned off = m < p.m ? ((unsigned)m * (unsigned)p.ldc + (unsigned)((n0 >> 1) + g * 2)) * 2u : DMA_OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(w, rs_c, off, j * 16, 0);
+        } else {
+          u32x2 w;
+          w[0] = pack2<DT>(v[0], v[1]);
+          w[1] = pack2<DT>(v[2], v[3]);
+          const unsigned off = m < p.m ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(n0 + g * 4)) * 2u : DMA_OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(w, rs_c, off, j * 32, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the row-bias patch is re-filled at the next slab's start)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two chunks fetched past the end
+}

@@ -57,8 +57,8 @@ def model_tree(tmp_path, monkeypatch):
     mm = {k: (torch.randn_like(v) * 0.02) for k, v in unet.state_dict().items() if "motion_modules" in k}
     torch.save({"state_dict": mm}, root / "mm_tiny.ckpt")
     # --- VAE
-    vae_cfg = dict(block_out_channels=(32, 64), layers_per_block=1, latent_channels=4, norm_num_groups=32,
-                   down_block_types=["DownEncoderBlock2D"] * 2, up_block_types=["UpDecoderBlock2D"] * 2)
+    vae_cfg = dict(block_out_channels=(32, 32, 64, 64), layers_per_block=1, latent_channels=4, norm_num_groups=32,
+                   down_block_types=["DownEncoderBlock2D"] * 4, up_block_types=["UpDecoderBlock2D"] * 4)
     vae = AutoencoderKL.from_config(vae_cfg)
     os.makedirs(base / "vae")
     json.dump(dict(vae_cfg, _class_name="AutoencoderKL"), open(base / "vae" / "config.json", "w"))
