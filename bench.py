@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0     # HBM3E, MI355X_MICROARCH.md
 
 # BASELINE.json configs.  tflop = algorithmic work per denoise step (2*MAC of conv, linear,
 # QK^T, PV): UNet3D + n_controlnets x ControlNet at the batch the reference feeds it (guess mode / native LCM: b = 1).
@@ -137,6 +138,8 @@ def tile_name(m: int, n: int, k: int, conv: bool) -> str:
     if k % 64:  # register-staged fallback kernel (conv_in, hint embedding)
         wide = n % 128 == 0 and cdiv(m, 128) * cdiv(n, 128) >= 512
         return "reg_128x128" if wide else "reg_128x64"
+    if (not conv) and k == 320 and n % 160 == 0 and n // 160 <= 32 and m >= 16384:
+        return "wres160"  # weight-resident streaming kernel (ca_gemm_wres.h): the K = 320 layers of the 64x64-latent level
     if conv and n % 128 == 0 and cdiv(m, 128) * (n // 128) < 384 and k // 64 >= 48:
         return "128x128_splitk"
     if n % 320 == 0 and k // 64 >= 10:  # ping-pong 128x320 kernel where the 128x128 grid under-fills the chip (ca_gemm.hip)
@@ -157,6 +160,8 @@ def rocprof_kernel_name(family: str, dtype: str) -> str:
     if tile.startswith("reg_"):
         return ""
     dt = 1 if dtype == "fp16" else 0
+    if tile == "wres160":
+        return f"k_gemm_wres<{dt}>"
     if tile == "pp128x320":
         return f"k_gemm_pp2<{dt}, {1 if op == 'conv3x3' else 0}"
     bm, bn = tile.replace("_splitk", "").split("x")
@@ -198,6 +203,7 @@ class KernelTimer:
     def __init__(self):
         self.records = []  # (variant, flops, start_event, end_event, shape)
         self.other = []
+        self.bytes = {}  # id(start event) -> algorithmic bytes of the launch
         self.enabled = False
 
     def install(self):
@@ -213,6 +219,9 @@ class KernelTimer:
             out = gemm0(a, w, **kw)
             e.record()
             m, n, k = a.shape[0], w.shape[0], w.shape[1]
+            # algorithmic bytes: every operand once (A, W, C, residual), 2 B per element
+            nb = 2.0 * (m * k + n * k + m * (n // 2 if kw.get("geglu") else n) + (m * n if kw.get("residual") is not None else 0))
+            timer.bytes[id(s)] = nb
             timer.records.append((f"gemm_{tile_name(m, n, k, False)}", 2.0 * m * n * k, s, e, (m, n, k)))
             return out
 
@@ -225,6 +234,7 @@ class KernelTimer:
             e.record()
             n = w.shape[0]
             mrows = out.shape[0] * out.shape[1] * out.shape[2]
+            timer.bytes[id(s)] = 2.0 * (x.numel() + (kw["x2"].numel() if kw.get("x2") is not None else 0) + w.numel() + out.numel())
             timer.records.append((f"conv3x3_{tile_name(mrows, n, 9 * w.shape[3], True)}", 2.0 * mrows * n * 9 * w.shape[3], s, e,
                                   (mrows, n, 9 * w.shape[3])))
             return out
@@ -274,9 +284,10 @@ class KernelTimer:
     def summary(self):
         agg = {}
         for name, flops, s, e, _shape in self.records:
-            d = agg.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+            d = agg.setdefault(name, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += self.bytes.get(id(s), 0.0)
             d["ms"] += s.elapsed_time(e)
         for d in agg.values():
             d["avg_us"] = 1e3 * d["ms"] / d["launches"]
@@ -634,13 +645,23 @@ def main():
             d = agg[dom]
             rname = rocprof_kernel_name(dom, args.dtype)
             traffic, traffic_src = pmc_traffic(rname, "config%d" % args.config if not custom else "custom", args.dtype)
-            out["roofline"] = {"bound": "mfma", "kernel": (f"k_gemm_pp2<{dom}>" if dom.endswith("pp128x320") else f"k_gemm_dma<{dom}>"), "rocprof_name": rname + "...>" if rname else None,
-                               "achieved": round(d["tflops"], 2), "peak": PEAK_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+            kname = f"k_gemm_wres<{dom}>" if dom.endswith("wres160") else (f"k_gemm_pp2<{dom}>" if dom.endswith("pp128x320") else f"k_gemm_dma<{dom}>")
+            # which roof bounds this instantiation's launch mix: algorithmic FLOP per algorithmic byte (every operand
+            # once) against the machine balance 2500 TFLOP/s : 8 TB/s = 312 FLOP/B
+            gbps = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+            hbm_bound = d["bytes"] > 0 and d["flops"] / d["bytes"] < PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)
+            mfma_view = {"achieved": round(d["tflops"], 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_MFMA_TFLOPS, 4)}
+            hbm_view = {"achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4)}
+            out["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname, "rocprof_name": rname + ("" if rname.endswith(">") else "...>") if rname else None,
+                               **(hbm_view if hbm_bound else mfma_view),
+                               "other_roof": mfma_view if hbm_bound else hbm_view,
+                               "traffic": traffic,
                                "traffic_unit": ("HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s: same workload and dtype)" % traffic_src)
                                if traffic is not None else "null: no committed PMC summary for this workload / dtype",
                                "launches": d["launches"], "avg_launch_us": round(d["avg_us"], 2),
                                "flop_per_launch": round(d["flops"] / d["launches"], 1),
+                               "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1),
+                               "flop_per_byte": round(d["flops"] / d["bytes"], 1) if d["bytes"] else None,
                                "share_of_step_time": round(d["ms"] * 1e-3 / roof_elapsed, 4),
                                "measured": "HIP events around every launch, instrumented pass of %d steps after the timed region" % min(args.steps, 5)}
             out["kernel_family"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2),

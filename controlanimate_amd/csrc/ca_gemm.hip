@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmKParams p) {
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   auto load_tile = [&](int t) {
-    int tap = (p.taps == 1) ? 0 : t / p.kc_tiles;
-    int cc = t - tap * p.kc_tiles;
+    int tap, cc;
+    k_tile_split(p, t, p.kc_tiles, tap, cc);
     int ci = cc * BK + lc * 8;
     bool cok = ci < kc;
     // weights
@@ -258,8 +258,8 @@ void k_gemm_dma(GemmKParams p) {
   auto stage = [&](int t, int buf) {
     u16* sa = smem + buf * (BM + BN) * KT;
     u16* sb = sa + BM * KT;
-    const int tap = (p.taps == 1) ? 0 : t / kct;
-    const int cc = t - tap * kct;
+    int tap, cc;
+    k_tile_split(p, t, kct, tap, cc);
     const int c0 = cc * KT;            // first channel of this K tile (tile-uniform)
     const bool src2 = c0 >= p.c1;      // c1 % 64 == 0 => a tile never straddles the two sources
     const int cs = src2 ? p.c2 : p.c1;
@@ -446,7 +446,8 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   }
   // Ping-pong kernels (ca_gemm_pp*.h; 8 waves, one block per CU, two wave groups alternating between an MFMA segment
   // and a fragment-read / DMA-issue segment, counted vmcnt).  CA_GEMM_PP: unset = heuristic below, 0 = never,
-  // 2 = 128x320 tiles whenever N % 320 == 0, 4 = the persistent variant with the pipelined epilogue (experimental),
+  // 2 = 128x320 tiles whenever N % 320 == 0, 4 = the persistent variant with the pipelined epilogue (experiment: see the
+  // warning at the top of ca_gemm_pp3.h),
   // 1 / 3 = the 256 x 256|128 variant (experimental).  Measured: the 128x320 tile divides every
   // channel count of the SD1.5 UNet exactly and wins where the 128x128 grid under-fills the chip (<= 2 rounds of
   // tiles: the 16x16- and 32x32-latent levels, +10..19%); with many rounds the exposed epilogue of a one-block-per-CU
@@ -657,6 +658,8 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
   p.c1 = a->cin1;
   p.c2 = a->cin2;
   p.taps = 9;
+  static const int tap_inner_env = getenv("CA_CONV_TAP_INNER") ? atoi(getenv("CA_CONV_TAP_INNER")) : 1;
+  p.tap_inner = tap_inner_env;  // (0: taps outermost, the round-1 order -- A/B experiments)
   p.kc_tiles = ceil_div_i(a->cin1 + a->cin2, BK);
   p.hin = a->hin;
   p.win = a->win;

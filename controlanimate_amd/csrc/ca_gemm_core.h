@@ -35,6 +35,7 @@ struct GemmKParams {
   int splits;
   float* partial;
   int dbg;  // timing experiments (CA_PP_DBG): 1 = no epilogue, 2 = no main loop
+  int tap_inner;  // K-tile order of the implicit-GEMM convolution (see k_tile_split)
 };
 
 constexpr int BK = 64;
@@ -55,6 +56,24 @@ __device__ __forceinline__ void tile_coords(unsigned bid, int tiles_m, int tiles
   const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
   tile_m = first_m + in % gm;
   tile_n = in / gm;
+}
+
+// K tile t of an implicit-GEMM 3x3 convolution -> (tap, 64-channel tile).  tap_inner: the nine taps of one channel
+// tile follow each other, so the ~4 input rows x 64 channels a block touches nine times stay in its XCD's L2 between
+// the touches (32 KB per block); with the taps outermost the whole channel depth (164 KB per block at C = 320, more
+// than the 4 MB L2 over the ~32 resident blocks of an XCD) passed between two touches and the counters showed the
+// activations fetched ~4.8x past L2 (profiles/round1_pmc_traffic.json).  Only the fp32 summation order changes.
+__device__ __forceinline__ void k_tile_split(const GemmKParams& p, int t, int kct, int& tap, int& cc) {
+  if (p.taps == 1) {
+    tap = 0;
+    cc = t;
+  } else if (p.tap_inner) {
+    cc = t / p.taps;
+    tap = t - cc * p.taps;
+  } else {
+    tap = t / kct;
+    cc = t - tap * kct;
+  }
 }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp(GemmKParams p) {
   auto issue = [&](int t, int kind) {
     if (t >= nt) return;
     u16* buf = smem + (t & 1) * BUF;
-    const int tap = (p.taps == 1) ? 0 : t / kct;
-    const int cc = t - tap * kct;
+    int tap, cc;
+    k_tile_split(p, t, kct, tap, cc);
     const int c0 = cc * KT;
     if ((kind & 1) == 0) {  // weights
       const int nh = kind >> 1;

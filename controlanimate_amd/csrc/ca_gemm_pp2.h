@@ -89,8 +89,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp2(GemmKParams p) {
   auto issue_ab0 = [&](int t) {  // units A and B0 of K tile t: 4 DMA instructions
     if (t >= nt) return;
     u16* buf = smem + (t & 1) * BUF;
-    const int tap = (p.taps == 1) ? 0 : t / kct;
-    const int c0 = (t - tap * kct) * KT;
+    int tap, cc;
+    k_tile_split(p, t, kct, tap, cc);
+    const int c0 = cc * KT;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned off = b0_off[i] + (unsigned)(tap * kc + c0 + b0_chunk[i] * 8) * 2u;
@@ -120,8 +121,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp2(GemmKParams p) {
   auto issue_b1 = [&](int t) {  // unit B1 of K tile t: 3 DMA instructions
     if (t >= nt) return;
     u16* buf = smem + (t & 1) * BUF;
-    const int tap = (p.taps == 1) ? 0 : t / kct;
-    const int c0 = (t - tap * kct) * KT;
+    int tap, cc;
+    k_tile_split(p, t, kct, tap, cc);
+    const int c0 = cc * KT;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const unsigned off = b1_off[i] + (unsigned)(tap * kc + c0 + b1_chunk[i] * 8) * 2u;

@@ -1,5 +1,13 @@
 // Persistent ping-pong GEMM / implicit-GEMM 3x3 convolution, 128 x 320 block tile, software-pipelined epilogue.
 //
+// EXPERIMENT (CA_GEMM_PP=4 only; never chosen by the heuristic).  Two findings keep it out of the default path
+// (DESIGN.md section 3): (1) the drain's VALU work sits inside a phase of the lock-stepped wave groups and costs more
+// than the exposed epilogue it replaces; (2) its counted waits treat the drain's stores as retiring in issue order with
+// the LDS-DMA loads -- the weight-resident kernel's experiments showed that stores retire OUT of order with respect to
+// loads (a vmcnt that leaves "the youngest N" outstanding may leave an OLDER load outstanding once stores are among
+// them), so a wait here can be satisfied before the operand unit it guards has landed.  The parity runs passed, but
+// that is timing luck, not a guarantee.
+//
 // Main loop = ca_gemm_pp2.h (8 waves = 2 groups x 4, per-wave 64 x 80, K tile = DMA units A | B0 | B1, two phases
 // per K tile, the groups one barrier apart, reads retired before the phase's first barrier).  What is new:
 //   * PERSISTENT: one block per CU walks tiles b, b+G, b+2G, ...; the operand stream (LDS-DMA) runs continuously

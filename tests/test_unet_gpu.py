@@ -16,9 +16,10 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 DEV = "cuda:0"
 SMALL = (64, 128, 256, 256)
 # fp16 (the shipped default, = the reference's .half()) must meet the north_star bound 1e-2 and
-# measures ~2.5e-3.  bf16 has 3 fewer mantissa bits: ~1.8e-2 after ~150 residual adds at these random
-# weights; it is an opt-in range-safe mode and is held to 3e-2 here (documented in DESIGN.md).
-TOL = {torch.bfloat16: 3e-2, torch.float16: 1e-2}
+# measures ~2.5e-3.  bf16: rounding ONLY the matrix-multiply operands of the exact fp32 oracle to bf16 already gives
+# 1.39e-2 on this fixture (tests/test_bf16_floor_cpu.py) -- no bf16-operand implementation can meet 1e-2 here; the
+# HIP path measures ~1.8e-2 and is held to 2.5e-2 (< 2x that floor).  bf16 is an opt-in range-safe mode.
+TOL = {torch.bfloat16: 2.5e-2, torch.float16: 1e-2}
 
 
 def load(name):
