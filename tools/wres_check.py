@@ -30,6 +30,8 @@ def cases(torch, dev, dt, small=False):
             st = torch.stack([a.float().mean(1), (a.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
             cs = w.float().sum(1).contiguous()
             out.append((f"LN fold {m}x{n}", dict(a=a, w=w, bias=bias, ln=(st, cs), residual=res)))
+            out.append((f"LN fold no-res {m}x{n}", dict(a=a, w=w, bias=bias, ln=(st, cs))))
+            out.append((f"silu post alpha {m}x{n}", dict(a=a, w=w, bias=bias, act=1, post_scale=0.5, alpha=1.25)))
             wide = rn(m, 1280).to(dt)
             out.append((f"strided A/C {m}x{n}", dict(a=wide[:, 320:640], w=w, residual=wide[:, 640:960], out=torch.zeros(m, 640, device=dev, dtype=dt)[:, 320:])))
     return out
@@ -99,7 +101,7 @@ if __name__ == "__main__":
         sys.exit(1 if run(sys.argv[1]) else 0)
     rc = 0
     for tag, env in (("wres", "1"), ("tiled", "0")):
-        e = dict(os.environ, CA_GEMM_WRES=env)
+        e = dict(os.environ, CA_GEMM_WRES=env)  # ("1": weight-resident / weights-in-registers kernels; "0": tiled kernels)
         rc |= subprocess.call([sys.executable, os.path.abspath(__file__), tag], env=e)
     import torch
     a, b = torch.load("/tmp/wres_wres.pt"), torch.load("/tmp/wres_tiled.pt")
