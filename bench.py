@@ -144,7 +144,7 @@ def tile_name(m: int, n: int, k: int, conv: bool) -> str:
         return "128x128_splitk"
     if n % 320 == 0 and k // 64 >= 10:  # ping-pong 128x320 kernel where the 128x128 grid under-fills the chip (ca_gemm.hip)
         tiles = cdiv(m, 128) * (n // 320)
-        if 128 <= tiles <= 256 or (tiles <= 512 and not conv and k // 64 >= 20):
+        if 128 <= tiles <= 256 or (128 <= tiles <= 512 and not conv):
             return "pp128x320"
     if (not conv) and n >= 5120 and k >= 640 and n % 128 == 0 and cdiv(m, 256) * (n // 128) >= 512:
         return "256x128"

@@ -104,7 +104,9 @@ class ControlAnimatePipeline:
                                                  tokenizer=components.get("tokenizer"), unet=unet, scheduler=scheduler).to(self.device)
         self.encode_prompt: Optional[Callable] = components.get("encode_prompt")
         if self.encode_prompt is None and self.pipeline.text_encoder is not None and self.pipeline.tokenizer is not None:
-            self.encode_prompt = self._encode_plain
+            # reference :133-135: Compel(tokenizer, text_encoder)(prompt) -- the configs' prompts use its weighting syntax
+            from .prompt_weighting import Compel
+            self.encode_prompt = Compel(tokenizer=self.pipeline.tokenizer, text_encoder=self.pipeline.text_encoder, device=self.device)
         self.use_ipadapter = bool(_get(config, "use_ipadapter", 0))
         if self.use_ipadapter:
             ip = IPAdapter(self.pipeline, components.get("image_encoder"), components.get("ip_adapter_ckpt"), self.device, num_tokens=4)

@@ -468,7 +468,7 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
                         p.a_bytes < 0x7FFFFF00u && p.w_bytes < 0x7FFFFF00u && (!p.c2 || p.a2_bytes < 0x7FFFFF00u);
     const bool pp3_ok = nt >= 5 && !p.out_f32 && fits32 && (!p.rowbias || p.rows_per_group % 64 == 0) && p.ldc % 8 == 0 && (!p.res || p.ld_res % 8 == 0);
     if (pp3_ok && pp_env == 4) return ca_launch_gemm_pp(p, DT, MODE, 321, (unsigned)tiles, st);
-    if (pp_env == 1 || pp_env == 2 || (pp_env < 0 && tiles >= 128 && nt >= 10 && (tiles <= 256 || (tiles <= 512 && MODE == 0 && nt >= 20))))
+    if (pp_env == 1 || pp_env == 2 || (pp_env < 0 && tiles >= 128 && nt >= 10 && (tiles <= 256 || (tiles <= 512 && MODE == 0))))
       return ca_launch_gemm_pp(p, DT, MODE, 320, (unsigned)tiles, st);
   }
   if (dma && (pp_env == 1 || pp_env == 3) && nt >= 2 && p.n % 128 == 0 && p.splits <= 1) {
