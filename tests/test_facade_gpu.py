@@ -13,13 +13,14 @@ SMALL = (64, 128, 256, 256)
 
 class _Tok:
     """Stand-in for CLIPTokenizer (host string processing): deterministic ids, BOS/EOS framing, 77 tokens."""
-    model_max_length = 77
+    model_max_length, bos_token_id, eos_token_id, pad_token_id = 77, 0, 99, 99
 
-    def __call__(self, text, padding=None, max_length=77, truncation=True, return_tensors="pt"):
+    def __call__(self, text, padding=None, max_length=77, truncation=True, return_tensors=None):
         ids = [0] + [3 + (ord(ch) % 90) for ch in text][: max_length - 2] + [99]
-        ids += [99] * (max_length - len(ids))
+        if padding == "max_length":
+            ids += [99] * (max_length - len(ids))
         from types import SimpleNamespace
-        return SimpleNamespace(input_ids=torch.tensor([ids]))
+        return SimpleNamespace(input_ids=torch.tensor([ids]) if return_tensors == "pt" else ids)
 
 
 def _components():
