@@ -60,7 +60,7 @@ class FeedForward(nn.Module):
         """With a folded LayerNorm `x` is the UN-normalised input."""
         fold = getattr(self, "fold", None)
         if fold is not None:
-            h = K.gemm(x, fold.w.t, bias=fold.b.t, geglu=True, ln=(K.row_stats(x, fold.eps), fold.cs.t))
+            h = K.gemm(x, fold.w.t, bias=fold.b.t, geglu=True, ln=(K.RowStats(x, fold.eps), fold.cs.t))
         else:
             h = self.net[0].run(x)
         return self.net[2].run(h, residual=residual)
@@ -108,13 +108,13 @@ class BasicTransformerBlock(nn.Module):
         """x: [images, tokens, C]."""
         B, N, C = x.shape
         if self.attn1.fold is not None:
-            x = self.attn1(x, residual=x, ln=(K.row_stats(x.view(B * N, C), self.norm1.eps), self.attn1.fold))
+            x = self.attn1(x, residual=x, ln=(K.RowStats(x.view(B * N, C), self.norm1.eps), self.attn1.fold))
         else:
             x = self.attn1(self.norm1.run(x.view(B * N, C)).view(B, N, C), residual=x)
         if self.attn2 is not None:
             kw = dict(encoder_hidden_states=ctx.ehs, residual=x, frames_per_kv=ctx.frames_per_kv, kv_mod=ctx.kv_mod, cache=ctx.cache)
             if self.attn2.fold is not None:
-                x = self.attn2(x, ln=(K.row_stats(x.view(B * N, C), self.norm2.eps), self.attn2.fold), **kw)
+                x = self.attn2(x, ln=(K.RowStats(x.view(B * N, C), self.norm2.eps), self.attn2.fold), **kw)
             else:
                 x = self.attn2(self.norm2.run(x.view(B * N, C)).view(B, N, C), **kw)
         x2 = x.view(B * N, C)

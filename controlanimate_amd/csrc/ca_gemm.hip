@@ -430,6 +430,20 @@ inline int splitk_plan(int m, int n, int nt, int geglu) {
   return s;
 }
 
+// Weight-resident streaming kernel (ca_gemm_wres.h) for the K = 320 GEMMs of the 64x64-latent level: does this dense
+// launch take it?  CA_GEMM_WRES: unset = on when M >= 16384 (measured: a tie at 32768 rows, ahead above), 0 = never,
+// 1 = whenever the shape qualifies.  (Also the condition under which ca_gemm can compute folded-LayerNorm statistics
+// itself: ca_gemm_ln_inline_supported.)
+inline bool wres_eligible(const GemmKParams& p) {
+  static const int wres_env = getenv("CA_GEMM_WRES") ? atoi(getenv("CA_GEMM_WRES")) : -1;
+  const int kc = p.c1 + p.c2;
+  return wres_env != 0 && kc == 320 && p.taps == 1 && (p.c2 == 0 || p.c1 % 32 == 0) && p.n % 160 == 0 && p.n / 160 <= 32 && !p.out_f32 &&
+         p.splits <= 1 && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0) && p.a_bytes < 0x7FFFFF00u &&
+         (!p.c2 || p.a2_bytes < 0x7FFFFF00u) && (!p.rowbias || p.rows_per_group % 32 == 0) &&
+         (((int64_t)p.m - 1) * p.ldc + (p.geglu ? p.n / 2 : p.n)) * 2 < 0x7FFFFF00ll && (!p.res || (((int64_t)p.m - 1) * p.ld_res + p.n) * 2 < 0x7FFFFF00ll) &&
+         (wres_env == 1 || p.m >= 16384);
+}
+
 template <int DT, int MODE>
 int launch_gemm(const GemmKParams& p, hipStream_t st) {
   const int kc = p.c1 + p.c2;
@@ -453,14 +467,7 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   // tiles: the 16x16- and 32x32-latent levels, +10..19%); with many rounds the exposed epilogue of a one-block-per-CU
   // kernel (35..45% of a K = 1280 GEMM) loses against 4 co-resident blocks of k_gemm_dma.
   static const int pp_env = getenv("CA_GEMM_PP") ? atoi(getenv("CA_GEMM_PP")) : -1;
-  // Weight-resident streaming kernel (ca_gemm_wres.h) for the K = 320 GEMMs of the 64x64-latent level.
-  // CA_GEMM_WRES: unset = on when M >= 16384 (measured: a tie at 32768 rows, ahead above), 0 = never, 1 = whenever the shape qualifies.
-  static const int wres_env = getenv("CA_GEMM_WRES") ? atoi(getenv("CA_GEMM_WRES")) : -1;
-  if (MODE == 0 && dma && wres_env != 0 && kc == 320 && p.taps == 1 && (p.c2 == 0 || p.c1 % 32 == 0) && p.n % 160 == 0 && p.n / 160 <= 32 &&
-      !p.out_f32 && p.splits <= 1 && p.a_bytes < 0x7FFFFF00u && (!p.c2 || p.a2_bytes < 0x7FFFFF00u) && (!p.rowbias || p.rows_per_group % 32 == 0) &&
-      (((int64_t)p.m - 1) * p.ldc + (p.geglu ? p.n / 2 : p.n)) * 2 < 0x7FFFFF00ll && (!p.res || (((int64_t)p.m - 1) * p.ld_res + p.n) * 2 < 0x7FFFFF00ll) &&
-      (wres_env == 1 || p.m >= 16384))
-    return ca_launch_gemm_pp(p, DT, MODE, 160, 0u, st);
+  if (MODE == 0 && dma && wres_eligible(p)) return ca_launch_gemm_pp(p, DT, MODE, 160, 0u, st);
   if (dma && pp_env != 0 && pp_env != 3 && nt >= 2 && p.n % 320 == 0 && p.splits <= 1) {  // 128 x 320 tiles
     const int64_t tiles = (int64_t)ceil_div_i(p.m, 128) * (p.n / 320);
     const int64_t ncols = p.geglu ? p.n / 2 : p.n;
@@ -557,7 +564,7 @@ int check_epilogue(const char* who, int n, int geglu, int out_f32, int64_t ldc, 
 
 }  // namespace
 
-extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
+static int gemm_fill(const ca_gemm_args* a, GemmKParams& p) {
   CA_REQUIRE(a != nullptr, "ca_gemm: null args");
   CA_REQUIRE(a->a && a->w && a->c, "ca_gemm: null operand");
   CA_REQUIRE(a->m > 0 && a->k1 > 0 && a->k2 >= 0, "ca_gemm: bad sizes m=%d k1=%d k2=%d", a->m, a->k1, a->k2);
@@ -568,7 +575,6 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   CA_REQUIRE(!a->rowbias || a->ld_rowbias % 4 == 0, "ca_gemm: ld_rowbias misaligned");
   int rc = check_epilogue("ca_gemm", a->n, a->geglu, a->out_f32, a->ldc, a->ld_res, a->residual);
   if (rc) return rc;
-  GemmKParams p{};
   p.a = (const u16*)a->a;
   p.a2 = (const u16*)a->a2;
   p.w = (const u16*)a->w;
@@ -577,8 +583,11 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   p.rowbias = a->rowbias;
   p.ln_stats = a->ln_stats;
   p.ln_colsum = a->ln_colsum;
-  CA_REQUIRE(!a->ln_stats == !a->ln_colsum, "ca_gemm: ln_stats and ln_colsum go together");
-  CA_REQUIRE(!a->ln_stats || (a->n >= 8 && a->k2 == 0), "ca_gemm: the folded LayerNorm needs N >= 8 and a single A source");
+  p.ln_inline = (a->ln_colsum && !a->ln_stats) ? 1 : 0;
+  p.ln_eps = a->ln_eps;
+  CA_REQUIRE(!a->ln_stats || a->ln_colsum, "ca_gemm: ln_stats without ln_colsum");
+  CA_REQUIRE(!p.ln_inline || a->ln_eps > 0.f, "ca_gemm: ln_colsum without ln_stats asks for in-kernel statistics and needs ln_eps > 0");
+  CA_REQUIRE(!a->ln_colsum || (a->n >= 8 && a->k2 == 0), "ca_gemm: the folded LayerNorm needs N >= 8 and a single A source");
   p.res = (const u16*)a->residual;
   p.lda = a->lda;
   p.lda2 = a->lda2;
@@ -601,11 +610,26 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   p.geglu = a->geglu;
   p.out_f32 = a->out_f32;
   p.splits = 1;
+  return CA_OK;
+}
+
+extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
+  GemmKParams p{};
+  int rc = gemm_fill(a, p);
+  if (rc) return rc;
+  CA_REQUIRE(!p.ln_inline || wres_eligible(p), "ca_gemm: in-kernel LayerNorm statistics (ln_stats NULL) are not available for this launch: "
+             "ask ca_gemm_ln_inline_supported() first and pass ln_stats otherwise");
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 0>(p, st);
   else launch_gemm<CA_F16, 0>(p, st);
   CA_CHECK_LAUNCH("ca_gemm");
   return CA_OK;
+}
+
+extern "C" int ca_gemm_ln_inline_supported(const ca_gemm_args* a) {
+  GemmKParams p{};
+  if (!a || !a->ln_colsum || gemm_fill(a, p) != CA_OK) return 0;
+  return wres_eligible(p) ? 1 : 0;
 }
 
 extern "C" int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* a) {

@@ -36,6 +36,8 @@ struct GemmKParams {
   float* partial;
   int dbg;  // timing experiments (CA_PP_DBG): 1 = no epilogue, 2 = no main loop
   int tap_inner;  // K-tile order of the implicit-GEMM convolution (see k_tile_split)
+  int ln_inline;  // ln_colsum without ln_stats: the kernel computes (mean, rstd) of the A rows itself (k_gemm_wres only)
+  float ln_eps;
 };
 
 constexpr int BK = 64;

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
     // LayerNorm statistics of this lane's two rows, and the row group's bias (one group per 32-row slab: the
     // launcher requires rows_per_group % 32 == 0) by LDS-DMA into the wave's patch -- both long landed at the epilogue
     float2 st[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    float ln_s[2] = {0.f, 0.f}, ln_ss[2] = {0.f, 0.f};
     if (p.ln_stats) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -152,13 +153,42 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
   acc[0][J] = Elem<DT>::mfma(fb[J], fa0, acc[0][J]);                \
   acc[1][J] = Elem<DT>::mfma(fb[J], fa1, acc[1][J]);                \
   __builtin_amdgcn_sched_barrier(0);
-      CA_WRES_PAIR(0, 9) CA_WRES_PAIR(1, 8) CA_WRES_PAIR(2, 7) CA_WRES_PAIR(3, 6) CA_WRES_PAIR(4, 5)
+      CA_WRES_PAIR(0, 9)
+      if (p.ln_inline) {
+        // LayerNorm statistics of the rows this wave streams anyway (ca_gemm_args.ln_eps): sum and sum of squares of
+        // this lane's 8-element slice of rows l15 and l15 + 16, in the shadow of the MFMAs; reduced over the four
+        // 8-element lane groups after the K loop.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // (v_dot2_f32_f16 via __builtin_amdgcn_fdot2 gave 7e-2 relative error here on gfx950 -- not pursued; plain
+          //  conversions + FMAs cost ~200 VALU cycles per chunk against 320 cycles of MFMA issue)
+          const float a0 = Elem<DT>::to_f((u16)(fa0[q] & 0xffffu)), a1 = Elem<DT>::to_f((u16)(fa0[q] >> 16));
+          const float b0 = Elem<DT>::to_f((u16)(fa1[q] & 0xffffu)), b1 = Elem<DT>::to_f((u16)(fa1[q] >> 16));
+          ln_s[0] += a0 + a1;
+          ln_ss[0] = fmaf(a0, a0, fmaf(a1, a1, ln_ss[0]));
+          ln_s[1] += b0 + b1;
+          ln_ss[1] = fmaf(b0, b0, fmaf(b1, b1, ln_ss[1]));
+        }
+      }
+      CA_WRES_PAIR(1, 8) CA_WRES_PAIR(2, 7) CA_WRES_PAIR(3, 6) CA_WRES_PAIR(4, 5)
       CA_WRES_PAIR(5, 4) CA_WRES_PAIR(6, 3) CA_WRES_PAIR(7, 2) CA_WRES_PAIR(8, 1) CA_WRES_PAIR(9, 0)
 #undef CA_WRES_PAIR
       // (lgkmcnt(0) above: every read of the slot has returned before the next issue() re-fills it)
       r_s = r_s == 2 ? 0 : r_s + 1;
     }
 
+    if (p.ln_inline) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float a = ln_s[i], b = ln_ss[i];
+        a += __shfl_xor(a, 16);
+        b += __shfl_xor(b, 16);
+        a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 32);
+        const float mean = a * (1.f / K);
+        st[i] = make_float2(mean, rsqrtf(fmaxf(b * (1.f / K) - mean * mean, 0.f) + p.ln_eps));  // (= k_ln_stats)
+      }
+    }
     // ---- epilogue of this wave's 32 x 160 patch, from the accumulators.  Every load is issued before the first
     // store (the VMEM counter is shared and in order: a load issued after a store could only be awaited together
     // with that store's completion): residual quads up front, LayerNorm statistics before the K loop, bias / column
@@ -178,7 +208,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
           rr[i][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, j * 32, 0));
         }
     }
-    if (!p.ln_stats && !p.rowbias && p.alpha == 1.f && p.post == 1.f && p.act == CA_ACT_NONE && !p.geglu) {
+    if (!p.ln_colsum && !p.rowbias && p.alpha == 1.f && p.post == 1.f && p.act == CA_ACT_NONE && !p.geglu) {
       // the common case (projections with bias and residual): ~12 VALU instructions per fragment instead of ~45 --
       // the epilogue's VALU time is of the order of the slab's MFMA time, and it is the part that does not scale away
       unsigned off[2];
@@ -221,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
       const int nl = j * 16 + g * 4;
       const f32x4 bi = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + nl * 4);
       f32x4 cs = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
-      if (p.ln_stats) cs = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (PN + nl) * 4);
+      if (p.ln_colsum) cs = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (PN + nl) * 4);
       if (p.rowbias) rb = *reinterpret_cast<const f32x4*>(rb_patch + nl * 4);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -229,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-        if (p.ln_stats) {
+        if (p.ln_colsum) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = st[i].y * (v[r] - st[i].x * cs[r]);
         }

@@ -75,10 +75,32 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
                     dtype=dt_code(a.dtype))
     if ln is not None:
         st, cs = ln
-        assert st.dtype == torch.float32 and st.shape == (m, 2) and st.is_contiguous() and cs.dtype == torch.float32 and cs.numel() == n
-        args.ln_stats, args.ln_colsum = _p(st), _p(cs)
+        assert cs.dtype == torch.float32 and cs.numel() == n
+        args.ln_colsum = _p(cs)
+        if isinstance(st, RowStats):  # statistics on demand: inside the GEMM where the library can, else the separate pass
+            assert st.x.data_ptr() == a.data_ptr() and st.x.shape == a.shape, "RowStats belongs to another tensor"
+            args.ln_eps = st.eps
+            if not lib().ca_gemm_ln_inline_supported(C.byref(args)):
+                st = st.tensor()
+        if not isinstance(st, RowStats):
+            assert st.dtype == torch.float32 and st.shape == (m, 2) and st.is_contiguous()
+            args.ln_stats = _p(st)
     check(lib().ca_gemm(C.byref(args), _stream()), "ca_gemm")
     return out
+
+
+class RowStats:
+    """LayerNorm statistics of the rows of `x`, not computed yet: `gemm(x, w, ln=(RowStats(x, eps), colsum))` lets the GEMM
+    compute them itself while it streams x (ca_gemm_args.ln_eps, ABI v6: the K = 320 weight-resident kernel) and falls
+    back to the separate pass (`row_stats`) where the library cannot."""
+
+    def __init__(self, x: torch.Tensor, eps: float = 1e-5):
+        self.x, self.eps, self._t = x, float(eps), None
+
+    def tensor(self) -> torch.Tensor:
+        if self._t is None:
+            self._t = row_stats(self.x, self.eps)
+        return self._t
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = None,

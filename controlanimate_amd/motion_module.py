@@ -103,7 +103,7 @@ class TemporalTransformerBlock(nn.Module):
         for attn, norm in zip(self.attention_blocks, self.norms):
             if attn.fold is not None:
                 x = attn(x.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens),
-                         ln=(K.row_stats(x, norm.eps), attn.fold)).view(rows, C)
+                         ln=(K.RowStats(x, norm.eps), attn.fold)).view(rows, C)
             else:
                 n = norm.run(x, pos=attn.pos_table(ctx.f), rows_per_frame=tokens, frames=ctx.f)
                 x = attn(n.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens)).view(rows, C)

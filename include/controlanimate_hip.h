@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 5
+#define CA_ABI_VERSION 6
 
 /* element types */
 #define CA_BF16 0
@@ -103,8 +103,16 @@ typedef struct ca_gemm_args {
    * un-normalised tensor: the normalised copy is never written or re-read. */
   const float* ln_stats;
   const float* ln_colsum;
+  /* ABI v6: `ln_colsum` set and `ln_stats` NULL = the kernel computes (mean, rstd = 1/sqrt(var + ln_eps)) of the A rows
+   * itself while it streams them -- the separate statistics pass over A (ca_layernorm `stats`) disappears.  Available
+   * only where ca_gemm_ln_inline_supported(args) returns 1 (the weight-resident K = 320 kernel of the 64x64-latent
+   * level); elsewhere ca_gemm returns CA_ERR_ARG and the caller passes ln_stats. */
+  float ln_eps;
 } ca_gemm_args;
 int ca_gemm(const ca_gemm_args* args, void* stream);
+/* 1 if ca_gemm can take these args with ln_stats == NULL (fields other than the pointers' values are what matters;
+ * no launch, no device access). */
+int ca_gemm_ln_inline_supported(const ca_gemm_args* args);
 
 /* ------------------------------------------------------------------------------------
  * ca_conv3x3: NHWC 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM

@@ -81,6 +81,16 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu(capi):
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=12, lda=16, ldc=16, dtype=1)), None), "ca_gemm")        # K % 8
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=16, lda=16, ldc=16, dtype=7)), None), "ca_gemm")        # dtype
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=16, lda=16, ldc=16, dtype=1, ln_stats=fake)), None), "ca_gemm")  # ln pair
+    # ABI v6: ln_colsum alone = statistics inside the kernel; only the weight-resident K = 320 kernel can (M >= 16384, N % 160 == 0)
+    def ln_args(m, n, k, eps=1e-5, **kw):
+        return capi.GemmArgs(a=fake, w=fake, c=fake, m=m, n=n, k1=k, lda=k, ldc=n, dtype=1, alpha=1.0, post_scale=1.0, ln_colsum=fake, ln_eps=eps, **kw)
+    assert lib.ca_gemm_ln_inline_supported(C.byref(ln_args(131072, 960, 320))) == 1
+    assert lib.ca_gemm_ln_inline_supported(C.byref(ln_args(131072, 960, 640))) == 0      # K != 320
+    assert lib.ca_gemm_ln_inline_supported(C.byref(ln_args(8192, 960, 320))) == 0        # too few rows for that kernel
+    assert lib.ca_gemm_ln_inline_supported(C.byref(ln_args(131072, 328, 320))) == 0      # N % 160
+    assert lib.ca_gemm_ln_inline_supported(None) == 0
+    expect(lib.ca_gemm(C.byref(ln_args(8192, 960, 320)), None), "ca_gemm")               # not available there: an error, not a silent fallback
+    expect(lib.ca_gemm(C.byref(ln_args(131072, 960, 320, eps=0.0)), None), "ca_gemm")    # needs ln_eps
     # N = 12 / ldc = 12 pass a "multiple of 4" check but the LDS-staged epilogue stores 16-byte chunks
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=12, k1=16, lda=16, ldc=16, dtype=1)), None), "ca_gemm")
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=16, lda=16, ldc=12, dtype=1)), None), "ca_gemm")

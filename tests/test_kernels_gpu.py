@@ -523,7 +523,8 @@ def test_lincomb_and_cfg_combined_eps():
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_weight_resident_k320(dtype):
     """The weight-resident streaming kernel (ca_gemm_wres.h; every K = 320 GEMM with M >= 16384 -- the 64x64-latent
-    level -- takes it): every epilogue it implements, ragged M, strided operands, both wave roles of the row-bias patch;
+    level -- takes it): every epilogue it implements, ragged M, strided operands, both wave roles of the row-bias patch,
+    folded-LayerNorm statistics computed inside the kernel (ABI v6) against the separate statistics pass;
     each case against an fp32 reference with the tiled kernels' rounding order, and bit-for-bit repeatable."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -531,7 +532,7 @@ def test_gemm_weight_resident_k320(dtype):
     k = _k()
     tol = 2e-3 if dtype == torch.float16 else 1.2e-2
     for name, kw in wres_check.cases(torch, "cuda", dtype, small=True):
-        outs = [k.gemm(**kw).clone() for _ in range(2)]
+        outs = [wres_check.call(k, kw).clone() for _ in range(2)]
         ref = wres_check.reference(torch, F, kw)
         rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
         assert torch.isfinite(outs[0].float()).all() and rel < tol, (name, rel)

@@ -31,6 +31,7 @@ def cases(torch, dev, dt, small=False):
             cs = w.float().sum(1).contiguous()
             out.append((f"LN fold {m}x{n}", dict(a=a, w=w, bias=bias, ln=(st, cs), residual=res)))
             out.append((f"LN fold no-res {m}x{n}", dict(a=a, w=w, bias=bias, ln=(st, cs))))
+            out.append((f"LN fold, statistics inside the GEMM {m}x{n}", dict(a=a, w=w, bias=bias, ln=("inline", cs), residual=res, _ln_ref=st)))
             out.append((f"silu post alpha {m}x{n}", dict(a=a, w=w, bias=bias, act=1, post_scale=0.5, alpha=1.25)))
             wide = rn(m, 1280).to(dt)
             out.append((f"strided A/C {m}x{n}", dict(a=wide[:, 320:640], w=w, residual=wide[:, 640:960], out=torch.zeros(m, 640, device=dev, dtype=dt)[:, 320:])))
@@ -44,6 +45,8 @@ def reference(torch, F, kw):
     dt = kw["a"].dtype
     if kw.get("ln") is not None:
         st, cs = kw["ln"]
+        if isinstance(st, str):
+            st = kw["_ln_ref"]
         a = (a - st[:, :1]) * st[:, 1:]
     y = a @ kw["w"].float().t()
     if kw.get("bias") is not None: y = y + kw["bias"]
@@ -57,6 +60,14 @@ def reference(torch, F, kw):
     return y
 
 
+def call(K, kw):
+    """K.gemm(**kw); ln=("inline", colsum) asks for the statistics inside the GEMM (K.RowStats)."""
+    kw = {k: v for k, v in kw.items() if not k.startswith("_")}
+    if kw.get("ln") is not None and isinstance(kw["ln"][0], str):
+        kw["ln"] = (K.RowStats(kw["a"], 1e-5), kw["ln"][1])
+    return K.gemm(**kw)
+
+
 def run(tag):
     import torch, torch.nn.functional as F
     from controlanimate_amd import kernels as K
@@ -65,7 +76,7 @@ def run(tag):
     saved = {}
     for dt in (torch.float16, torch.bfloat16):
         for name, kw in cases(torch, dev, dt):
-            outs = [K.gemm(**kw).clone() for _ in range(3)]
+            outs = [call(K, kw).clone() for _ in range(3)]
             ref = reference(torch, F, kw)
             rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
             same = all(torch.equal(outs[0], o) for o in outs[1:])
