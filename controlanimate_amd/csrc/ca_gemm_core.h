@@ -124,8 +124,9 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmKParams& p, f32x4
         for (int r = 0; r < 4; ++r) v[r] = act_f(v[r], p.act);
       }
       if (p.geglu) {
-        float o0 = v[0] * gelu_erf_f(v[1]);
-        float o1 = v[2] * gelu_erf_f(v[3]);
+        const f32x2 gg = gelu_erf_f2((f32x2){v[1], v[3]});
+        float o0 = v[0] * gg[0];
+        float o1 = v[2] * gg[1];
         const int64_t off = (int64_t)m * p.ldc + (n >> 1);
         if (p.out_f32) {
           float* cp = reinterpret_cast<float*>(p.c) + off;
@@ -256,7 +257,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
     if (p.geglu) {
       float o[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = v[2 * k] * gelu_erf_f(v[2 * k + 1]);
+      for (int k = 0; k < 4; k += 2) {
+        const f32x2 gg = gelu_erf_f2((f32x2){v[2 * k + 1], v[2 * k + 3]});
+        o[k] = v[2 * k] * gg[0];
+        o[k + 1] = v[2 * k + 2] * gg[1];
+      }
       const int64_t off = (int64_t)m * p.ldc + (n >> 1);
       if (p.out_f32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + off) = (f32x4){o[0], o[1], o[2], o[3]};

@@ -279,7 +279,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
         }
         // (rows past M: the offset is out of the descriptor's range, the hardware drops the store)
         if (p.geglu) {
-          const unsigned w = pack2<DT>(v[0] * gelu_erf_f(v[1]), v[2] * gelu_erf_f(v[3]));
+          const f32x2 gg = gelu_erf_f2((f32x2){v[1], v[3]});
+          const unsigned w = pack2<DT>(v[0] * gg[0], v[2] * gg[1]);
           const unsigned off = m < p.m ? ((unsigned)m * (unsigned)p.ldc + (unsigned)((n0 >> 1) + g * 2)) * 2u : DMA_OOB;
           __builtin_amdgcn_raw_buffer_store_b32(w, rs_c, off, j * 16, 0);
         } else {
