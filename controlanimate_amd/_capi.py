@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("alpha", C.c_float), ("post_scale", C.c_float),
         ("act", C.c_int32), ("geglu", C.c_int32), ("out_f32", C.c_int32), ("dtype", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -93,6 +94,7 @@ SYMBOLS = {
     "ca_last_error": (C.c_char_p, []),
     "ca_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "ca_gemm_ln_inline_supported": (C.c_int, [C.POINTER(GemmArgs)]),
+    "ca_gemm_workspace_bytes": (C.c_int64, [C.POINTER(GemmArgs)]),
     "ca_conv3x3": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "ca_conv3x3_workspace_bytes": (C.c_int64, [C.POINTER(ConvArgs)]),
     "ca_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_float, C.c_int32, C.c_void_p]),

@@ -383,6 +383,11 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmKParams p) {
       v[4 + k] += b[k];
     }
   }
+  if (p.ln_stats) {  // folded LayerNorm: rstd * (x W'^T - mean * colsum(W'))
+    const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + m * 2);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = st.y * (v[k] - st.x * p.ln_colsum[n + k]);
+  }
   if (p.bias) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] += p.bias[n + k];
@@ -442,6 +447,21 @@ inline bool wres_eligible(const GemmKParams& p) {
          (!p.c2 || p.a2_bytes < 0x7FFFFF00u) && (!p.rowbias || p.rows_per_group % 32 == 0) &&
          (((int64_t)p.m - 1) * p.ldc + (p.geglu ? p.n / 2 : p.n)) * 2 < 0x7FFFFF00ll && (!p.res || (((int64_t)p.m - 1) * p.ld_res + p.n) * 2 < 0x7FFFFF00ll) &&
          (wres_env == 1 || p.m >= 16384);
+}
+
+// Dense GEMMs of the 8x8-latent level (M = 2048: 160 tiles of 128x128 for 256 CUs, each walking its 20..80 K tiles
+// alone at one DMA round trip per tile): the same slab schedule as the small convolutions.  CA_SPLITK_DENSE=0 disables.
+inline int splitk_plan_dense(int m, int n, int nt, int geglu, int out_f32) {
+  static const int env = getenv("CA_SPLITK_DENSE") ? atoi(getenv("CA_SPLITK_DENSE")) : -1;
+  if (env == 0 || geglu || out_f32 || n % 128 != 0) return 1;
+  const int64_t blocks = (int64_t)ceil_div_i(m, 128) * (n / 128);
+  // (measured: 2048x1280x5120, 80 K tiles: 55 vs 61 us; 2048x1280x1280, 20 K tiles: 34 vs 19 us -- the fp32 slabs and the
+  //  second launch cost more than a short K loop saves, hence the same threshold as the convolutions)
+  if (blocks > 192 || nt < 48) return 1;
+  int s = env > 0 ? env : (int)((960 + blocks - 1) / blocks);
+  if (s > 8) s = 8;
+  while (s > 1 && nt / s < 12) --s;
+  return s;
 }
 
 template <int DT, int MODE>
@@ -617,6 +637,14 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   GemmKParams p{};
   int rc = gemm_fill(a, p);
   if (rc) return rc;
+  {
+    const bool dma_ok = (a->k1 + a->k2) % BK == 0 && (a->k2 == 0 || a->k1 % BK == 0);
+    const int s = dma_ok && !p.ln_inline ? splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) : 1;
+    if (s > 1 && a->workspace && a->workspace_bytes >= (int64_t)s * p.m * p.n * 4) {
+      p.splits = s;
+      p.partial = reinterpret_cast<float*>(a->workspace);
+    }
+  }
   CA_REQUIRE(!p.ln_inline || wres_eligible(p), "ca_gemm: in-kernel LayerNorm statistics (ln_stats NULL) are not available for this launch: "
              "ask ca_gemm_ln_inline_supported() first and pass ln_stats otherwise");
   hipStream_t st = (hipStream_t)stream;
@@ -624,6 +652,14 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   else launch_gemm<CA_F16, 0>(p, st);
   CA_CHECK_LAUNCH("ca_gemm");
   return CA_OK;
+}
+
+extern "C" int64_t ca_gemm_workspace_bytes(const ca_gemm_args* a) {
+  if (!a || a->m <= 0 || a->n <= 0 || a->k1 <= 0 || a->k2 < 0) return 0;
+  const int kc = a->k1 + a->k2;
+  if (kc % BK != 0 || (a->k2 != 0 && a->k1 % BK != 0) || (a->ln_colsum && !a->ln_stats)) return 0;
+  const int s = splitk_plan_dense(a->m, a->n, ceil_div_i(kc, BK), a->geglu, a->out_f32);
+  return s > 1 ? (int64_t)s * a->m * a->n * 4 : 0;
 }
 
 extern "C" int ca_gemm_ln_inline_supported(const ca_gemm_args* a) {

@@ -85,6 +85,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         if not isinstance(st, RowStats):
             assert st.dtype == torch.float32 and st.shape == (m, 2) and st.is_contiguous()
             args.ln_stats = _p(st)
+    wbytes = int(lib().ca_gemm_workspace_bytes(C.byref(args)))
+    if wbytes > 0:  # split-K slabs for the 8x8-latent level (allocator-cached, stream-ordered)
+        ws = torch.empty((wbytes,), device=a.device, dtype=torch.uint8)
+        args.workspace, args.workspace_bytes = _p(ws), wbytes
     check(lib().ca_gemm(C.byref(args), _stream()), "ca_gemm")
     return out
 

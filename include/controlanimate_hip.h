@@ -108,8 +108,15 @@ typedef struct ca_gemm_args {
    * only where ca_gemm_ln_inline_supported(args) returns 1 (the weight-resident K = 320 kernel of the 64x64-latent
    * level); elsewhere ca_gemm returns CA_ERR_ARG and the caller passes ln_stats. */
   float ln_eps;
+  /* ABI v6: optional split-K scratch (device memory, caller-owned, may be shared by every call on one stream) of at
+   * least ca_gemm_workspace_bytes(args) bytes, or NULL / too small: the GEMM then runs unsplit -- same results up to
+   * fp32 summation order, only slower on grids that under-fill the chip (M = 2048: the 8x8-latent level). */
+  void* workspace;
+  int64_t workspace_bytes;
 } ca_gemm_args;
 int ca_gemm(const ca_gemm_args* args, void* stream);
+/* bytes of split-K scratch this launch can use (0: it would not split) */
+int64_t ca_gemm_workspace_bytes(const ca_gemm_args* args);
 /* 1 if ca_gemm can take these args with ln_stats == NULL (fields other than the pointers' values are what matters;
  * no launch, no device access). */
 int ca_gemm_ln_inline_supported(const ca_gemm_args* args);

@@ -60,6 +60,10 @@ GEMM_CASES = [
     (16384, 960, 320, 0, False, False, False, 1.0, 1.0, 0, False, False),
     (16384, 1280, 1280, 0, True, True, True, 1.0, 1.0, 0, False, False),
     (65536, 320, 640, 640, True, False, False, 1.0, 1.0, 0, False, False),
+    # <= 192 tiles of 128x128 with >= 16 K tiles: the split-K slab schedule of the 8x8-latent level (ABI v6 workspace)
+    (2048, 1280, 1280, 0, True, False, True, 1.0, 1.0, 0, False, False),
+    (2040, 1280, 5120, 0, True, True, True, 0.5, 0.7, 1, False, False),
+    (300, 1280, 1024, 1024, True, False, False, 1.0, 1.0, 0, False, False),
 ]
 
 
@@ -328,7 +332,7 @@ def test_attention_causal(images, tokens, heads, d, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,n,k,geglu,rb", [(300, 960, 320, False, False), (4096, 2560, 320, True, False), (512, 640, 640, False, True),
-                                             (77, 1280, 1280, False, False)])
+                                             (77, 1280, 1280, False, False), (2048, 1280, 1280, False, False)])  # last: split-K reduce
 def test_gemm_with_folded_layernorm(m, n, k, geglu, rb, dtype):
     """LN(x) W^T + b == rstd * (x W'^T - mean * colsum(W')) + (W beta + b), W' = W diag(gamma):
     ca_layernorm(stats) + ca_gemm(ln_stats, ln_colsum) against LayerNorm -> Linear in fp32."""
