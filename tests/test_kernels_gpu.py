@@ -332,7 +332,7 @@ def test_attention_causal(images, tokens, heads, d, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,n,k,geglu,rb", [(300, 960, 320, False, False), (4096, 2560, 320, True, False), (512, 640, 640, False, True),
-                                             (77, 1280, 1280, False, False), (2048, 1280, 1280, False, False)])  # last: split-K reduce
+                                             (77, 1280, 1280, False, False), (2048, 1280, 3072, False, False)])  # last: 48 K tiles on 160 tiles -> split-K reduce
 def test_gemm_with_folded_layernorm(m, n, k, geglu, rb, dtype):
     """LN(x) W^T + b == rstd * (x W'^T - mean * colsum(W')) + (W beta + b), W' = W diag(gamma):
     ca_layernorm(stats) + ca_gemm(ln_stats, ln_colsum) against LayerNorm -> Linear in fp32."""
@@ -356,9 +356,12 @@ def test_gemm_with_folded_layernorm(m, n, k, geglu, rb, dtype):
     wp = wf.to(dtype)
     cs = wp.float().sum(1)
     xd = x.to(DEV)
-    st = k_.row_stats(xd, 1e-5)
     ref_st = torch.stack([x.float().mean(1), (x.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1)
-    assert torch.allclose(st.cpu(), ref_st, rtol=2e-4, atol=2e-5)
+    if k <= 2048:
+        st = k_.row_stats(xd, 1e-5)
+        assert torch.allclose(st.cpu(), ref_st, rtol=2e-4, atol=2e-5)
+    else:  # (the statistics kernel stops at 2048 channels; the GEMM takes caller-computed statistics of any width)
+        st = ref_st.contiguous().to(DEV)
     out = k_.gemm(xd, wp.to(DEV), bias=bf.to(DEV), geglu=geglu, ln=(st, cs.to(DEV)),
                   rowbias=None if rowbias is None else rowbias.to(DEV), rows_per_group=m // 4 if rb else 0)
     torch.cuda.synchronize()
