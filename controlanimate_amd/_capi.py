@@ -101,6 +101,7 @@ SYMBOLS = {
     "ca_groupnorm_partials_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ca_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),
     "ca_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),
+    "ca_groupnorm": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),
     "ca_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "ca_attention": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "ca_add_bcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),

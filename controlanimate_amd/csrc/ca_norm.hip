@@ -1,6 +1,7 @@
 // GroupNorm(+SiLU) and LayerNorm(+positional table) for channels-last activations (gfx950).
 // Both are HBM-bound: 16-byte vector accesses, fp32 statistics, wavefront (64-lane) shuffles.
 #include "ca_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -307,6 +308,92 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
   }
 }
 
+// One launch for small statistics groups (the 8x8- and 16x16-latent levels: two launches of ~8 us each for 5-20 MB):
+// one block per (statistics group, norm group) keeps that group's rows x channels in registers between the two passes
+// -- read once, statistics, normalise, write.  Needs cpg % 8 == 0 (a 16-byte chunk inside one norm group: cpg = 40 / 80)
+// and rows * cpg / 8 <= 256 * GNS_MAX chunks.  Deterministic (fixed shuffle tree, ordered LDS pass, fp64 finish).
+constexpr int GNS_MAX = 12;
+template <int DT>
+__global__ __launch_bounds__(256) void k_gn_small(GnParams p) {
+  __shared__ double red[4][2];
+  __shared__ float mr[2];
+  const int C = p.c1 + p.c2;
+  const int cpg = C / p.groups, q = cpg >> 3;
+  const int g = blockIdx.x, sg = blockIdx.y;
+  const int total = (int)p.rows_per_stat * q;
+  const int64_t base_row = (int64_t)sg * p.rows_per_stat;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4 raw[GNS_MAX];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < GNS_MAX; ++k) {
+    const int id = threadIdx.x + k * 256;
+    if (id < total) {
+      const int row = id / q, ch = g * cpg + (id - row * q) * 8;
+      const int64_t rr = base_row + row;
+      raw[k] = ld16(ch < p.c1 ? p.x + rr * p.c1 + ch : p.x2 + rr * p.c2 + (ch - p.c1));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < GNS_MAX; ++k) {
+    if (threadIdx.x + k * 256 < total) {
+      float f[8];
+      unpack8<DT>(raw[k], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s += f[j];
+        ss += f[j] * f[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    s += __shfl_xor(s, off);
+    ss += __shfl_xor(ss, off);
+  }
+  if (lane == 0) {
+    red[wave][0] = (double)s;
+    red[wave][1] = (double)ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double a = red[0][0] + red[1][0] + red[2][0] + red[3][0], b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    const double cnt = (double)p.rows_per_stat * (double)cpg;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[0] = (float)mean;
+    mr[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  const float mean = mr[0], rstd = mr[1];
+#pragma unroll
+  for (int k = 0; k < GNS_MAX; ++k) {
+    const int id = threadIdx.x + k * 256;
+    if (id < total) {
+      const int row = id / q, ch = g * cpg + (id - row * q) * 8;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + ch), g1 = *reinterpret_cast<const f32x4*>(p.gamma + ch + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + ch), b1 = *reinterpret_cast<const f32x4*>(p.beta + ch + 4);
+      float f[8];
+      unpack8<DT>(raw[k], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float scale = rstd * (j < 4 ? g0[j & 3] : g1[j & 3]);
+        const float v = f[j] * scale + ((j < 4 ? b0[j & 3] : b1[j & 3]) - mean * scale);
+        f[j] = p.act == CA_ACT_SILU ? silu_f(v) : v;
+      }
+      st16(p.y + (base_row + row) * C + ch, pack8<DT>(f));
+    }
+  }
+}
+
+inline bool gn_small_ok(const GnParams& p) {
+  static const int env = getenv("CA_GN_FUSED") ? atoi(getenv("CA_GN_FUSED")) : 1;  // 0: always the two-kernel path
+  const int C = p.c1 + p.c2, cpg = C / p.groups;
+  return env && p.y && cpg % 8 == 0 && (p.c2 == 0 || p.c1 % cpg == 0) && p.rows_per_stat * (cpg >> 3) <= 256 * GNS_MAX;
+}
+
+
 int gn_fill(const ca_groupnorm_args* a, GnParams& p, const char* who) {
   CA_REQUIRE(a != nullptr, "%s: null args", who);
   CA_REQUIRE(a->x && a->partials, "%s: null operand", who);
@@ -594,6 +681,25 @@ extern "C" int ca_groupnorm_apply(const ca_groupnorm_args* a, void* stream) {
   else launch_gn<CA_F16>(true, p, grid, (hipStream_t)stream);
   CA_CHECK_LAUNCH("ca_groupnorm_apply");
   return CA_OK;
+}
+
+// GroupNorm in one call: the fused single-launch kernel where a statistics group fits a block's registers, otherwise
+// statistics + apply (needs `partials`).
+extern "C" int ca_groupnorm(const ca_groupnorm_args* a, void* stream) {
+  GnParams p{};
+  int rc = gn_fill(a, p, "ca_groupnorm");
+  if (rc) return rc;
+  CA_REQUIRE(a->y && a->gamma && a->beta, "ca_groupnorm: null operand");
+  if (gn_small_ok(p)) {
+    const dim3 grid(p.groups, a->images / a->frames_per_stat);
+    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_gn_small<CA_BF16>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_gn_small<CA_F16>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    CA_CHECK_LAUNCH("ca_groupnorm");
+    return CA_OK;
+  }
+  rc = ca_groupnorm_stats(a, stream);
+  if (rc) return rc;
+  return ca_groupnorm_apply(a, stream);
 }
 
 extern "C" int ca_layernorm(const ca_layernorm_args* a, void* stream) {

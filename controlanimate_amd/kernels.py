@@ -168,9 +168,7 @@ def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, x2: 
     args = GroupNormArgs(x=_p(x), x2=_p(x2), y=_p(y), gamma=_p(gamma), beta=_p(beta), partials=_p(partials),
                          images=images, hw=h * w_, c1=c1, c2=c2, groups=groups,
                          frames_per_stat=frames_per_stat, eps=eps, act=act, dtype=dt_code(x.dtype))
-    st = _stream()
-    check(lib().ca_groupnorm_stats(C.byref(args), st), "ca_groupnorm_stats")
-    check(lib().ca_groupnorm_apply(C.byref(args), st), "ca_groupnorm_apply")
+    check(lib().ca_groupnorm(C.byref(args), _stream()), "ca_groupnorm")
     return y
 
 

@@ -198,6 +198,9 @@ typedef struct ca_groupnorm_args {
 int64_t ca_groupnorm_partials_floats(int32_t images, int32_t hw, int32_t frames_per_stat, int32_t groups);
 int ca_groupnorm_stats(const ca_groupnorm_args* args, void* stream);
 int ca_groupnorm_apply(const ca_groupnorm_args* args, void* stream);
+/* ABI v6: both passes in one call; small statistics groups (8x8 / 16x16 latents) run as ONE launch that keeps the
+ * group in registers between the passes.  `partials` as above (unused by the fused kernel, still required). */
+int ca_groupnorm(const ca_groupnorm_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * ca_layernorm: y[r,:] = LN(x[r,:]) * gamma + beta (+ pos[(r / rows_per_frame) % frames, :])
