@@ -473,6 +473,22 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   static const int bn_env = getenv("CA_GEMM_BN") ? atoi(getenv("CA_GEMM_BN")) : 0;
   const int nt = p.taps * p.kc_tiles;
   if (dma && p.splits > 1) {
+    // dense only: 128x320 ping-pong tiles -- the pipelined K loop needs fewer blocks to cover the DMA latency, so fewer
+    // (larger) K ranges and slabs: 2048x1280x5120 in 4 ranges x 64 tiles 45 vs 52 us.  (The 8x8-latent convolution
+    // 2048x1280x11520 measured 88 vs 82 us this way and stays on the 128x128 schedule.)
+    static const int pp_split_env = getenv("CA_SPLITK_PP") ? atoi(getenv("CA_SPLITK_PP")) : 1;
+    if (pp_split_env && MODE == 0 && p.n % 320 == 0) {
+      const int tiles320 = ceil_div_i(p.m, 128) * (p.n / 320);
+      int s_eff = 256 / tiles320;
+      if (s_eff > p.splits) s_eff = p.splits;
+      if (s_eff >= 2 && tiles320 * s_eff >= 128 && nt / s_eff >= 12) {
+        GemmKParams q = p;
+        q.splits = s_eff;
+        const int rc = ca_launch_gemm_pp(q, DT, MODE, 320, (unsigned)(tiles320 * s_eff), st);
+        hipLaunchKernelGGL((k_splitk_reduce<DT>), dim3(ceil_div_i((int64_t)q.m * (q.n / 8), 256)), dim3(256), 0, st, q);
+        return rc;
+      }
+    }
     const int tiles = ceil_div_i(p.m, 128) * (p.n / 128);
     hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 1>), dim3(tiles * p.splits), dim3(256), 0, st, p);
     hipLaunchKernelGGL((k_splitk_reduce<DT>), dim3(ceil_div_i((int64_t)p.m * (p.n / 8), 256)), dim3(256), 0, st, p);

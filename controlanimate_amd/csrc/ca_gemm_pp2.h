@@ -29,7 +29,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp2(GemmKParams p) {
 
   const int tiles_n = p.n / BN;
   const int tiles_m = (p.m + BM - 1) / BM;
-  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  int split = 0;
+  if (p.splits > 1) {  // split-K (small-M convolutions): consecutive ids = the tiles of ONE K range; fp32 slab instead of the epilogue
+    split = bid / (unsigned)(tiles_m * tiles_n);
+    bid -= split * (unsigned)(tiles_m * tiles_n);
+  }
   int tile_m, tile_n;
   tile_coords(bid, tiles_m, tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -84,13 +89,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp2(GemmKParams p) {
     b1_off[i] = (unsigned)(n0 + (r / 48) * 80 + 32 + r % 48) * wld * 2u;
   }
 
-  const int nt = p.taps * kct;
+  const int nt_all = p.taps * kct;
+  const int t_first = p.splits > 1 ? (int)((int64_t)nt_all * split / p.splits) : 0;
+  const int nt = (p.splits > 1 ? (int)((int64_t)nt_all * (split + 1) / p.splits) : nt_all) - t_first;  // K tiles of this block: local index 0..nt-1
 
   auto issue_ab0 = [&](int t) {  // units A and B0 of K tile t: 4 DMA instructions
     if (t >= nt) return;
     u16* buf = smem + (t & 1) * BUF;
     int tap, cc;
-    k_tile_split(p, t, kct, tap, cc);
+    k_tile_split(p, t_first + t, kct, tap, cc);
     const int c0 = cc * KT;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp2(GemmKParams p) {
     if (t >= nt) return;
     u16* buf = smem + (t & 1) * BUF;
     int tap, cc;
-    k_tile_split(p, t, kct, tap, cc);
+    k_tile_split(p, t_first + t, kct, tap, cc);
     const int c0 = cc * KT;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -222,6 +229,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp2(GemmKParams p) {
   __syncthreads();
   if (p.dbg == 1) {
     if (acc[0][0][0] == 12345.678f) *reinterpret_cast<float*>(p.c) = acc[3][1][2] + acc[2][TN - 1][1];
+    return;
+  }
+  if (p.splits > 1) {  // raw fp32 slab; lane holds C[m = .. + l15][n = .. + 4g + (0..3)]
+    float* slab = p.partial + (int64_t)split * p.m * p.n;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + l15;
+      if (m >= p.m) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(slab + (int64_t)m * p.n + n0 + wc * 80 + j * 16 + g * 4) = acc[i][j];
+    }
     return;
   }
   gemm_epilogue<DT, BM, BN, TM, TN, 512>(p, acc, smem, m0, n0, wr, wc, l15, g, tid);

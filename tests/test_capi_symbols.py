@@ -104,6 +104,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu(capi):
     assert lib.ca_conv3x3_workspace_bytes(C.byref(small)) == 6 * 2048 * 1280 * 4        # 160 tiles -> 6 K ranges of fp32 slabs
     big = capi.ConvArgs(images=32, hin=64, win=64, cin1=320, cout=320, stride=1, dtype=1)
     assert lib.ca_conv3x3_workspace_bytes(C.byref(big)) == 0
+    expect(lib.ca_groupnorm(None, None), "ca_groupnorm")
+    expect(lib.ca_groupnorm(C.byref(capi.GroupNormArgs(x=fake, partials=fake, images=2, hw=16, c1=64, groups=32, frames_per_stat=1, dtype=1)), None), "ca_groupnorm")  # y / gamma / beta missing
     expect(lib.ca_groupnorm_stats(C.byref(capi.GroupNormArgs(x=fake, partials=fake, images=2, hw=16, c1=30, groups=32, frames_per_stat=1, dtype=1)), None),
            "ca_groupnorm_stats")                                                                               # C % 8
     expect(lib.ca_groupnorm_apply(C.byref(capi.GroupNormArgs(x=fake, partials=fake, images=3, hw=16, c1=64, groups=32, frames_per_stat=2, dtype=1)), None),
