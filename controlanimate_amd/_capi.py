@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("act", C.c_int32), ("geglu", C.c_int32), ("out_f32", C.c_int32), ("dtype", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("row_sums_out", C.c_void_p), ("ln_parts", C.c_int32),
     ]
 
 
@@ -95,6 +96,7 @@ SYMBOLS = {
     "ca_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "ca_gemm_ln_inline_supported": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_gemm_workspace_bytes": (C.c_int64, [C.POINTER(GemmArgs)]),
+    "ca_gemm_row_sums_parts": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_conv3x3": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "ca_conv3x3_workspace_bytes": (C.c_int64, [C.POINTER(ConvArgs)]),
     "ca_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_float, C.c_int32, C.c_void_p]),

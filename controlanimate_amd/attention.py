@@ -56,11 +56,11 @@ class FeedForward(nn.Module):
             self.net[0].pack(arena, dtype)
         self.net[2].pack(arena, dtype)
 
-    def run(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """With a folded LayerNorm `x` is the UN-normalised input."""
+    def run(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, sums=None) -> torch.Tensor:
+        """With a folded LayerNorm `x` is the UN-normalised input (`sums`: row sums its producer left, K.row_sums_of)."""
         fold = getattr(self, "fold", None)
         if fold is not None:
-            h = K.gemm(x, fold.w.t, bias=fold.b.t, geglu=True, ln=(K.RowStats(x, fold.eps), fold.cs.t))
+            h = K.gemm(x, fold.w.t, bias=fold.b.t, geglu=True, ln=(K.RowStats(x, fold.eps, sums), fold.cs.t))
         else:
             h = self.net[0].run(x)
         return self.net[2].run(h, residual=residual)
@@ -107,20 +107,24 @@ class BasicTransformerBlock(nn.Module):
     def forward(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
         """x: [images, tokens, C]."""
         B, N, C = x.shape
+        # (each projection that feeds a folded LayerNorm is asked for the row sums of its output: K.gemm(row_sums=True))
+        next_folded = (self.attn2.fold if self.attn2 is not None else self.ff.fold) is not None
         if self.attn1.fold is not None:
-            x = self.attn1(x, residual=x, ln=(K.RowStats(x.view(B * N, C), self.norm1.eps), self.attn1.fold))
+            x = self.attn1(x, residual=x, ln=(K.RowStats(x.view(B * N, C), self.norm1.eps, K.row_sums_of(x)), self.attn1.fold),
+                           row_sums=next_folded)
         else:
-            x = self.attn1(self.norm1.run(x.view(B * N, C)).view(B, N, C), residual=x)
+            x = self.attn1(self.norm1.run(x.view(B * N, C)).view(B, N, C), residual=x, row_sums=next_folded)
         if self.attn2 is not None:
-            kw = dict(encoder_hidden_states=ctx.ehs, residual=x, frames_per_kv=ctx.frames_per_kv, kv_mod=ctx.kv_mod, cache=ctx.cache)
+            kw = dict(encoder_hidden_states=ctx.ehs, residual=x, frames_per_kv=ctx.frames_per_kv, kv_mod=ctx.kv_mod, cache=ctx.cache,
+                      row_sums=self.ff.fold is not None)
             if self.attn2.fold is not None:
-                x = self.attn2(x, ln=(K.RowStats(x.view(B * N, C), self.norm2.eps), self.attn2.fold), **kw)
+                x = self.attn2(x, ln=(K.RowStats(x.view(B * N, C), self.norm2.eps, K.row_sums_of(x)), self.attn2.fold), **kw)
             else:
                 x = self.attn2(self.norm2.run(x.view(B * N, C)).view(B, N, C), **kw)
         x2 = x.view(B * N, C)
         if self.ff.fold is None:
             return self.ff.run(self.norm3.run(x2), residual=x2).view(B, N, C)
-        return self.ff.run(x2, residual=x2).view(B, N, C)
+        return self.ff.run(x2, residual=x2, sums=K.row_sums_of(x)).view(B, N, C)
 
 
 class Transformer3DModel(nn.Module):
@@ -150,7 +154,8 @@ class Transformer3DModel(nn.Module):
         images, h, w, c = x.shape
         rows = images * h * w
         y = self.norm.run(x)  # always per image (reference rearranges to (b f) first, attention.py:124)
-        y = self.proj_in.run(y.view(rows, c)).view(images, h * w, -1)
+        y0 = self.proj_in.run(y.view(rows, c), row_sums=self.transformer_blocks[0].attn1.fold is not None)
+        y = K.carry_row_sums(y0.view(images, h * w, -1), y0)
         for blk in self.transformer_blocks:
             y = blk(y, ctx)
         return self.proj_out.run(y.view(rows, -1), residual=x.view(rows, c)).view(images, h, w, c)

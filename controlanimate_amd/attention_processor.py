@@ -37,7 +37,7 @@ class AttnProcessor2_0(nn.Module):
 
     def __call__(self, attn: "Attention", hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
                  attention_mask=None, temb=None, *, residual: Optional[torch.Tensor] = None, frames_per_kv: int = 1,
-                 kv_mod: int = 0, temporal=None, cache: Optional[dict] = None, ln=None) -> torch.Tensor:
+                 kv_mod: int = 0, temporal=None, cache: Optional[dict] = None, ln=None, row_sums: bool = False) -> torch.Tensor:
         """ln = (row statistics, LnFold): `hidden_states` is then the UN-normalised tensor and the LayerNorm that
         precedes this attention is folded into the q / q|k|v projection (built-in processors only)."""
         if attention_mask is not None:
@@ -72,8 +72,9 @@ class AttnProcessor2_0(nn.Module):
             nk = L - self.num_tokens
             o = K.attention_cross(q, kv, B, N, attn.heads, nk, L, frames_per_kv, kv_mod=kv_mod)
             o = self.ip_branch(attn, q, ctx, o, B, N, L, frames_per_kv, kv_mod, cache)
-        out = attn.to_out[0].run(o, residual=res)
-        return out.reshape(B, N, C)
+        # row_sums: the output feeds a folded LayerNorm next -- its statistics come out of this GEMM's epilogue where it can
+        out = attn.to_out[0].run(o, residual=res, row_sums=row_sums)
+        return K.carry_row_sums(out.reshape(B, N, C), out)
 
 
 class IPAttnProcessor2_0(AttnProcessor2_0):

@@ -464,6 +464,17 @@ inline int splitk_plan_dense(int m, int n, int nt, int geglu, int out_f32) {
   return s;
 }
 
+// Dense launches the heuristic below sends to the 128 x 320 ping-pong kernel (whose epilogue can leave per-row sums of
+// its output: ca_gemm_args.row_sums_out).  Same conditions as in launch_gemm.
+inline bool pp2_default_dense(const GemmKParams& p) {
+  static const int pp_env = getenv("CA_GEMM_PP") ? atoi(getenv("CA_GEMM_PP")) : -1;
+  const int kc = p.c1 + p.c2;
+  const bool dma = kc % BK == 0 && (p.c2 == 0 || p.c1 % BK == 0) && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0);
+  if (!dma || p.taps != 1 || p.splits > 1 || wres_eligible(p) || p.n % 320 != 0 || p.kc_tiles < 2 || (pp_env != -1 && pp_env != 2)) return false;
+  const int64_t tiles = (int64_t)ceil_div_i(p.m, 128) * (p.n / 320);
+  return pp_env == 2 || (tiles >= 128 && p.kc_tiles >= 10 && tiles <= 512);
+}
+
 template <int DT, int MODE>
 int launch_gemm(const GemmKParams& p, hipStream_t st) {
   const int kc = p.c1 + p.c2;
@@ -619,6 +630,10 @@ static int gemm_fill(const ca_gemm_args* a, GemmKParams& p) {
   p.rowbias = a->rowbias;
   p.ln_stats = a->ln_stats;
   p.ln_colsum = a->ln_colsum;
+  p.row_sums = a->row_sums_out;
+  p.ln_parts = a->ln_parts;
+  CA_REQUIRE(a->ln_parts >= 0 && a->ln_parts <= 16, "ca_gemm: ln_parts=%d", a->ln_parts);
+  CA_REQUIRE(a->ln_parts == 0 || (a->ln_stats && a->ln_colsum && a->ln_eps > 0.f), "ca_gemm: ln_parts needs ln_stats (the partial sums), ln_colsum and ln_eps > 0");
   p.ln_inline = (a->ln_colsum && !a->ln_stats) ? 1 : 0;
   p.ln_eps = a->ln_eps;
   CA_REQUIRE(!a->ln_stats || a->ln_colsum, "ca_gemm: ln_stats without ln_colsum");
@@ -655,12 +670,13 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   if (rc) return rc;
   {
     const bool dma_ok = (a->k1 + a->k2) % BK == 0 && (a->k2 == 0 || a->k1 % BK == 0);
-    const int s = dma_ok && !p.ln_inline ? splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) : 1;
+    const int s = dma_ok && !p.ln_inline && !p.row_sums ? splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) : 1;
     if (s > 1 && a->workspace && a->workspace_bytes >= (int64_t)s * p.m * p.n * 4) {
       p.splits = s;
       p.partial = reinterpret_cast<float*>(a->workspace);
     }
   }
+  CA_REQUIRE(!p.row_sums || (pp2_default_dense(p) && !p.geglu && !p.out_f32), "ca_gemm: row_sums_out is not available for this launch: ask ca_gemm_row_sums_parts() first");
   CA_REQUIRE(!p.ln_inline || wres_eligible(p), "ca_gemm: in-kernel LayerNorm statistics (ln_stats NULL) are not available for this launch: "
              "ask ca_gemm_ln_inline_supported() first and pass ln_stats otherwise");
   hipStream_t st = (hipStream_t)stream;
@@ -676,6 +692,18 @@ extern "C" int64_t ca_gemm_workspace_bytes(const ca_gemm_args* a) {
   if (kc % BK != 0 || (a->k2 != 0 && a->k1 % BK != 0) || (a->ln_colsum && !a->ln_stats)) return 0;
   const int s = splitk_plan_dense(a->m, a->n, ceil_div_i(kc, BK), a->geglu, a->out_f32);
   return s > 1 ? (int64_t)s * a->m * a->n * 4 : 0;
+}
+
+extern "C" int ca_gemm_row_sums_parts(const ca_gemm_args* a) {
+  GemmKParams p{};
+  if (!a || a->geglu || a->out_f32) return 0;
+  ca_gemm_args b = *a;
+  b.row_sums_out = nullptr;  // (the question is about the launch, whatever the pointer)
+  if (gemm_fill(&b, p) != CA_OK) return 0;
+  const int kc = a->k1 + a->k2;
+  const bool dma_ok = kc % BK == 0 && (a->k2 == 0 || a->k1 % BK == 0);
+  if (dma_ok && !p.ln_inline && a->workspace && splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) > 1) return 0;
+  return pp2_default_dense(p) ? p.n / 320 : 0;
 }
 
 extern "C" int ca_gemm_ln_inline_supported(const ca_gemm_args* a) {

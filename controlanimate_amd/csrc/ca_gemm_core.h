@@ -36,6 +36,8 @@ struct GemmKParams {
   float* partial;
   int dbg;  // timing experiments (CA_PP_DBG): 1 = no epilogue, 2 = no main loop
   int tap_inner;  // K-tile order of the implicit-GEMM convolution (see k_tile_split)
+  float* row_sums;  // producer side: [M][N / 320] (sum, sum of squares) of the STORED output rows per 320-column tile (k_gemm_pp2 only)
+  int ln_parts;     // consumer side: ln_stats holds [M][ln_parts] such partial sums, finished here with ln_eps; 0: (mean, rstd)
   int ln_inline;  // ln_colsum without ln_stats: the kernel computes (mean, rstd) of the A rows itself (k_gemm_wres only)
   float ln_eps;
 };
@@ -156,9 +158,12 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmKParams& p, f32x4
 // at this point (the loop ends with a barrier).  Staged value = (acc + bias + rowbias) * alpha
 // rounded to the activation type; the residual is added in fp32 afterwards (the reference's fp16
 // pipeline rounds at the same place: linear output, then `+ hidden_states`).
-template <int DT, int BM, int BN, int TM, int TN, int NT = 256>
+// ROWSUM (k_gemm_pp2): besides storing, leave (sum, sum of squares) of every stored row's BN columns in p.row_sums --
+// the LayerNorm statistics of the NEXT layer without its pass over the tensor (ca_gemm_args.row_sums_out).  `rs` is LDS
+// scratch of BM x BN/8 float2 behind the staging tile; fixed summation order (deterministic).
+template <int DT, int BM, int BN, int TM, int TN, int NT = 256, bool ROWSUM = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)[TM][TN], u16* cs, int m0, int n0, int wm, int wn,
-                                              int l15, int g, int tid) {
+                                              int l15, int g, int tid, float2* rs = nullptr) {
   if (p.n < 8) {  // conv_out (Cout = 4)
     gemm_epilogue_direct<DT, TM, TN>(p, acc, m0, n0, wm, wn, l15, g);
     return;
@@ -171,7 +176,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + wm * TM * 16 + i * 16 + l15;
-      ln_st[i] = m < p.m ? *reinterpret_cast<const float2*>(p.ln_stats + (int64_t)m * 2) : make_float2(0.f, 0.f);
+      if (p.ln_parts > 0) {  // partial sums left by the producing GEMM's epilogue: finish (mean, rstd) here, in order
+        float a = 0.f, b = 0.f;
+        if (m < p.m) {
+          for (int q = 0; q < p.ln_parts; ++q) {
+            const float2 v = *reinterpret_cast<const float2*>(p.ln_stats + ((int64_t)m * p.ln_parts + q) * 2);
+            a += v.x;
+            b += v.y;
+          }
+        }
+        const float inv = 1.f / (float)(p.c1 + p.c2);
+        const float mean = a * inv;
+        ln_st[i] = make_float2(mean, rsqrtf(fmaxf(b * inv - mean * mean, 0.f) + p.ln_eps));
+      } else {
+        ln_st[i] = m < p.m ? *reinterpret_cast<const float2*>(p.ln_stats + (int64_t)m * 2) : make_float2(0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -278,8 +297,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
       } else {
-        st16(reinterpret_cast<u16*>(p.c) + off, pack8<DT>(v));
+        const u32x4 pk = pack8<DT>(v);
+        st16(reinterpret_cast<u16*>(p.c) + off, pk);
+        if (ROWSUM && p.row_sums) {  // of the values as stored (rounded)
+          float r[8];
+          unpack8<DT>(pk, r);
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            a += r[k];
+            b = fmaf(r[k], r[k], b);
+          }
+          rs[row * CH + c8] = make_float2(a, b);
+        }
       }
+    }
+  }
+  if (ROWSUM && p.row_sums) {
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.m) {
+      float a = 0.f, b = 0.f;
+      for (int c8 = 0; c8 < CH; ++c8) {
+        const float2 v = rs[tid * CH + c8];
+        a += v.x;
+        b += v.y;
+      }
+      *reinterpret_cast<float2*>(p.row_sums + ((int64_t)(m0 + tid) * (p.n / BN) + n0 / BN) * 2) = make_float2(a, b);
     }
   }
 }

@@ -18,7 +18,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp2(GemmKParams p) {
   constexpr int A_ROWS = 128, B0_ROWS = 128, B1_ROWS = 192;
   constexpr int OFF_A = 0, OFF_B0 = A_ROWS * KT, OFF_B1 = (A_ROWS + B0_ROWS) * KT;
   constexpr int BUF = (A_ROWS + B0_ROWS + B1_ROWS) * KT;  // elements: 56 KB
-  constexpr int SMEM_ELEMS = 2 * BUF > BM * (BN + 8) ? 2 * BUF : BM * (BN + 8);
+  constexpr int RS_ELEMS = BM * (BN / 8) * 4;  // row-sum scratch of the epilogue (float2 per row and 16-byte chunk), in u16 units
+  constexpr int SMEM_ELEMS = 2 * BUF > BM * (BN + 8) + RS_ELEMS ? 2 * BUF : BM * (BN + 8) + RS_ELEMS;
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_ELEMS];
 
   const int tid = threadIdx.x;
@@ -242,5 +243,5 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp2(GemmKParams p) {
     }
     return;
   }
-  gemm_epilogue<DT, BM, BN, TM, TN, 512>(p, acc, smem, m0, n0, wr, wc, l15, g, tid);
+  gemm_epilogue<DT, BM, BN, TM, TN, 512, true>(p, acc, smem, m0, n0, wr, wc, l15, g, tid, reinterpret_cast<float2*>(smem + BM * (BN + 8)));
 }

@@ -6,6 +6,7 @@ torch is used only for device memory and streams; every arithmetic op below is a
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -44,7 +45,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
          bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
          rows_per_group: int = 0, residual: Optional[torch.Tensor] = None, alpha: float = 1.0,
          post_scale: float = 1.0, act: int = ACT_NONE, geglu: bool = False, out_f32: bool = False,
-         out: Optional[torch.Tensor] = None, ln=None) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, ln=None, row_sums: bool = False) -> torch.Tensor:
     """out[M, N] = epilogue(cat(a, a2)[M, K] @ w[N, K]^T); see ca_gemm in the header.
     ln = (row_stats(a), colsum(w) fp32 [N]): LayerNorm of `a` folded in (w, bias packed accordingly)."""
     _req_cuda(a, w, a2, bias, rowbias, residual, out)
@@ -77,15 +78,28 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         st, cs = ln
         assert cs.dtype == torch.float32 and cs.numel() == n
         args.ln_colsum = _p(cs)
-        if isinstance(st, RowStats):  # statistics on demand: inside the GEMM where the library can, else the separate pass
+        if isinstance(st, RowStats):  # statistics on demand: inside the GEMM where the library can, else the partial
+            # sums the producing GEMM left (row_sums=True), else the separate pass
             assert st.x.data_ptr() == a.data_ptr() and st.x.shape == a.shape, "RowStats belongs to another tensor"
             args.ln_eps = st.eps
-            if not lib().ca_gemm_ln_inline_supported(C.byref(args)):
+            if lib().ca_gemm_ln_inline_supported(C.byref(args)):
+                pass
+            elif st.sums is not None:
+                rs, parts = st.sums
+                assert rs.shape == (m, parts, 2) and rs.dtype == torch.float32 and rs.is_contiguous()
+                args.ln_stats, args.ln_parts = _p(rs), parts
+            else:
                 st = st.tensor()
         if not isinstance(st, RowStats):
             assert st.dtype == torch.float32 and st.shape == (m, 2) and st.is_contiguous()
             args.ln_stats = _p(st)
-    wbytes = int(lib().ca_gemm_workspace_bytes(C.byref(args)))
+    if row_sums and _ROW_SUMS_ON and not geglu and not out_f32:
+        parts = int(lib().ca_gemm_row_sums_parts(C.byref(args)))
+        if parts > 0:  # the epilogue leaves (sum, sum of squares) per row and 320-column tile: the next LayerNorm's statistics
+            rs = torch.empty((m, parts, 2), device=a.device, dtype=torch.float32)
+            args.row_sums_out = _p(rs)
+            out._row_sums = (rs, parts)
+    wbytes = 0 if args.row_sums_out else int(lib().ca_gemm_workspace_bytes(C.byref(args)))
     if wbytes > 0:  # split-K slabs for the 8x8-latent level (allocator-cached, stream-ordered)
         ws = torch.empty((wbytes,), device=a.device, dtype=torch.uint8)
         args.workspace, args.workspace_bytes = _p(ws), wbytes
@@ -93,13 +107,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     return out
 
 
+_ROW_SUMS_ON = os.environ.get("CA_LN_ROWSUMS", "1") != "0"  # (0: always the separate statistics pass -- A/B runs)
+
+
+def row_sums_of(t: torch.Tensor):
+    """The partial row sums the GEMM that produced `t` left for the next LayerNorm, or None."""
+    return getattr(t, "_row_sums", None)
+
+
+def carry_row_sums(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """`dst` is a view of `src` (same rows): keep the producer's row sums attached."""
+    s = getattr(src, "_row_sums", None)
+    if s is not None:
+        dst._row_sums = s
+    return dst
+
+
 class RowStats:
     """LayerNorm statistics of the rows of `x`, not computed yet: `gemm(x, w, ln=(RowStats(x, eps), colsum))` lets the GEMM
     compute them itself while it streams x (ca_gemm_args.ln_eps, ABI v6: the K = 320 weight-resident kernel) and falls
     back to the separate pass (`row_stats`) where the library cannot."""
 
-    def __init__(self, x: torch.Tensor, eps: float = 1e-5):
-        self.x, self.eps, self._t = x, float(eps), None
+    def __init__(self, x: torch.Tensor, eps: float = 1e-5, sums=None):
+        # sums = (partial sums [rows, parts, 2], parts) left by the GEMM that produced x (gemm(..., row_sums=True))
+        self.x, self.eps, self._t, self.sums = x, float(eps), None, sums
 
     def tensor(self) -> torch.Tensor:
         if self._t is None:

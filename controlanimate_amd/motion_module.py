@@ -100,16 +100,21 @@ class TemporalTransformerBlock(nn.Module):
     def forward(self, x: torch.Tensor, ctx: ExecCtx, tokens: int) -> torch.Tensor:
         """x: [(b f n), C] rows."""
         rows, C = x.shape
-        for attn, norm in zip(self.attention_blocks, self.norms):
+        nblk = len(self.attention_blocks)
+        for i, (attn, norm) in enumerate(zip(self.attention_blocks, self.norms)):
+            # the next folded LayerNorm (the following attention's, or the feed-forward's) takes its statistics from this
+            # projection's epilogue where the library can (K.gemm(row_sums=True))
+            nxt = (self.attention_blocks[i + 1].fold if i + 1 < nblk else self.ff.fold) is not None
             if attn.fold is not None:
-                x = attn(x.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens),
-                         ln=(K.RowStats(x, norm.eps), attn.fold)).view(rows, C)
+                o = attn(x.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens),
+                         ln=(K.RowStats(x, norm.eps, K.row_sums_of(x)), attn.fold), row_sums=nxt)
             else:
                 n = norm.run(x, pos=attn.pos_table(ctx.f), rows_per_frame=tokens, frames=ctx.f)
-                x = attn(n.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens)).view(rows, C)
+                o = attn(n.view(1, rows, C), residual=x.view(1, rows, C), temporal=(ctx.b, ctx.f, tokens), row_sums=nxt)
+            x = K.carry_row_sums(o.view(rows, C), o)
         if self.ff.fold is None:
             return self.ff.run(self.ff_norm.run(x), residual=x)
-        return self.ff.run(x, residual=x)
+        return self.ff.run(x, residual=x, sums=K.row_sums_of(x))
 
 
 class TemporalTransformer3DModel(nn.Module):
@@ -134,7 +139,7 @@ class TemporalTransformer3DModel(nn.Module):
         images, h, w, c = x.shape
         rows = images * h * w
         y = self.norm.run(x)  # per image ('(b f) c h w', motion_module.py:139-144)
-        y = self.proj_in.run(y.view(rows, c))
+        y = self.proj_in.run(y.view(rows, c), row_sums=self.transformer_blocks[0].attention_blocks[0].fold is not None)
         for blk in self.transformer_blocks:
             y = blk(y, ctx, h * w)
         return self.proj_out.run(y, residual=x.view(rows, c)).view(images, h, w, c)

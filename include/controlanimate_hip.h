@@ -113,10 +113,20 @@ typedef struct ca_gemm_args {
    * fp32 summation order, only slower on grids that under-fill the chip (M = 2048: the 8x8-latent level). */
   void* workspace;
   int64_t workspace_bytes;
+  /* ABI v6: LayerNorm statistics handed from the producing GEMM to the consuming one, without a pass over the tensor.
+   *   producer: `row_sums_out` [M][P][2] fp32, P = ca_gemm_row_sums_parts(args) = N / 320 > 0: the epilogue also writes
+   *             (sum, sum of squares) of every STORED output row per 320-column tile (the 128x320-tile kernel only;
+   *             0 from the query = not available for this launch, do not set the pointer);
+   *   consumer: `ln_parts` = P and `ln_stats` = that array instead of (mean, rstd): the epilogue adds the P partial
+   *             sums in order and finishes mean / rstd = 1 / sqrt(var + ln_eps) itself (K of the consumer = the row width). */
+  float* row_sums_out;
+  int32_t ln_parts;
 } ca_gemm_args;
 int ca_gemm(const ca_gemm_args* args, void* stream);
 /* bytes of split-K scratch this launch can use (0: it would not split) */
 int64_t ca_gemm_workspace_bytes(const ca_gemm_args* args);
+/* partial sums per row this launch can leave in row_sums_out (0: it cannot) */
+int ca_gemm_row_sums_parts(const ca_gemm_args* args);
 /* 1 if ca_gemm can take these args with ln_stats == NULL (fields other than the pointers' values are what matters;
  * no launch, no device access). */
 int ca_gemm_ln_inline_supported(const ca_gemm_args* args);

@@ -544,3 +544,35 @@ def test_gemm_weight_resident_k320(dtype):
         rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
         assert torch.isfinite(outs[0].float()).all() and rel < tol, (name, rel)
         assert torch.equal(outs[0], outs[1]), name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,c", [(8192, 1280), (32768 - 24, 640)])
+def test_layernorm_statistics_handed_from_producer_to_consumer(m, c, dtype):
+    """ABI v6 row_sums_out / ln_parts: the GEMM that writes a tensor leaves (sum, sum of squares) of every stored row per
+    320-column tile; the GEMM with the folded LayerNorm of that tensor finishes mean / rstd from them -- same result as
+    with the separate statistics pass, which is skipped."""
+    k = _k()
+    a = rnd(m, c, dtype=dtype, seed=71).to(DEV)
+    w = rnd(c, c, dtype=torch.float32, scale=c ** -0.5, seed=72).to(dtype).to(DEV)
+    res = (rnd(m, c, dtype=torch.float32, seed=73) * 1.5 + 0.7).to(dtype).to(DEV)
+    x = k.gemm(a, w, residual=res, row_sums=True)
+    sums = k.row_sums_of(x)
+    assert sums is not None, "the 128x320-tile kernel takes this shape: row sums expected"
+    rs, parts = sums
+    assert parts == c // 320 and rs.shape == (m, parts, 2)
+    xf = x.float().view(m, parts, 320)
+    assert torch.allclose(rs[..., 0], xf.sum(-1), rtol=1e-4, atol=2e-2) and torch.allclose(rs[..., 1], (xf * xf).sum(-1), rtol=1e-4, atol=2e-2)
+    n = 3 * c
+    w2 = rnd(n, c, dtype=torch.float32, scale=c ** -0.5, seed=74).to(dtype).to(DEV)
+    cs = w2.float().sum(1).contiguous()
+    bias = rnd(n, dtype=torch.float32, seed=75).to(DEV)
+    y_sep = k.gemm(x, w2, bias=bias, ln=(k.row_stats(x, 1e-5), cs))
+    y_new = k.gemm(x, w2, bias=bias, ln=(k.RowStats(x, 1e-5, sums), cs))
+    torch.cuda.synchronize()
+    ref = F.linear(F.layer_norm(x.float(), (c,), eps=1e-5), w2.float(), bias)
+    close(y_new, ref.cpu(), dtype, f"ln via producer sums ({m},{c})")
+    assert ((y_new.float() - y_sep.float()).abs().max() <= 4 * 2.0 ** (-8 if dtype == torch.bfloat16 else -10) * ref.abs().max()).item()
+    # a shape the 128x320 kernel does not take: no sums, and asking for them in the C call is an error, not a fallback
+    small = k.gemm(a[:256], w, row_sums=True)
+    assert k.row_sums_of(small) is None
