@@ -91,6 +91,19 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu(capi):
     assert lib.ca_gemm_ln_inline_supported(None) == 0
     expect(lib.ca_gemm(C.byref(ln_args(8192, 960, 320)), None), "ca_gemm")               # not available there: an error, not a silent fallback
     expect(lib.ca_gemm(C.byref(ln_args(131072, 960, 320, eps=0.0)), None), "ca_gemm")    # needs ln_eps
+    # ABI v6: row sums for the next LayerNorm out of the 128x320-tile kernel's epilogue; split-K scratch for long-K dense GEMMs
+    def plain(m, n, k, **kw):
+        return capi.GemmArgs(a=fake, w=fake, c=fake, m=m, n=n, k1=k, lda=k, ldc=n, dtype=1, alpha=1.0, post_scale=1.0, **kw)
+    assert lib.ca_gemm_row_sums_parts(C.byref(plain(8192, 1280, 1280))) == 4        # 256 tiles of 128x320
+    assert lib.ca_gemm_row_sums_parts(C.byref(plain(32768, 640, 640))) == 2
+    assert lib.ca_gemm_row_sums_parts(C.byref(plain(2048, 1280, 1280))) == 0        # 64 tiles: another kernel takes it
+    assert lib.ca_gemm_row_sums_parts(C.byref(plain(131072, 320, 320))) == 0        # the weight-resident kernel takes it
+    assert lib.ca_gemm_row_sums_parts(C.byref(plain(8192, 1280, 1280, geglu=1))) == 0
+    expect(lib.ca_gemm(C.byref(plain(2048, 1280, 1280, row_sums_out=fake)), None), "ca_gemm")          # not available: an error
+    expect(lib.ca_gemm(C.byref(plain(8192, 1280, 1280, ln_parts=4)), None), "ca_gemm")                 # ln_parts without the sums
+    assert lib.ca_gemm_workspace_bytes(C.byref(plain(2048, 1280, 5120))) == 6 * 2048 * 1280 * 4        # 80 K tiles on 160 tiles
+    assert lib.ca_gemm_workspace_bytes(C.byref(plain(2048, 1280, 1280))) == 0                          # 20 K tiles: not worth it
+    assert lib.ca_gemm_workspace_bytes(None) == 0
     # N = 12 / ldc = 12 pass a "multiple of 4" check but the LDS-staged epilogue stores 16-byte chunks
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=12, k1=16, lda=16, ldc=16, dtype=1)), None), "ca_gemm")
     expect(lib.ca_gemm(C.byref(capi.GemmArgs(a=fake, w=fake, c=fake, m=16, n=16, k1=16, lda=16, ldc=12, dtype=1)), None), "ca_gemm")
