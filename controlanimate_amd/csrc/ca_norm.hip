@@ -387,6 +387,131 @@ __global__ __launch_bounds__(256) void k_gn_small(GnParams p) {
   }
 }
 
+// The same one-launch scheme for the 10- and 20-channel groups of the 64x64- and 32x32-latent levels, where a 16-byte
+// chunk straddles norm groups: a block owns a UNIT of UC = lcm(cpg, 8) channels (40: four or two groups) of one statistics
+// group, 1024 threads x up to 20 chunks in registers (64x64 latents: 4096 rows x 5 chunks exactly).  Read once, write
+// once: 168 MB instead of 252 MB at [32, 64, 64, 320].  The units of one image sit on one XCD (their 80-byte pieces
+// share 128-byte lines).  A chunk touches at most two groups: (first part, second part) sums as in k_gn_stats.
+constexpr int GNU_MAX = 20;
+template <int DT>
+__global__ __launch_bounds__(1024) void k_gn_unit(GnParams p, int uc, int units) {
+  __shared__ float red[16][4][2];
+  __shared__ float mr[4][2];
+  __shared__ __attribute__((aligned(16))) float sc[128], sh[128];
+  const int C = p.c1 + p.c2;
+  const int cpg = C / p.groups, q = uc >> 3, ug = uc / cpg;  // chunks per row and unit, groups per unit
+  // block -> (unit, statistics group): the `units` units of a statistics group on one XCD (round-robin dispatch)
+  const unsigned bid = blockIdx.x;
+  const int nstat = gridDim.x / units;
+  int unit, sg;
+  if (nstat % 8 == 0) {
+    unit = (bid >> 3) % units;
+    sg = (bid & 7) + 8 * (bid / (8 * units));
+  } else {
+    unit = bid % units;
+    sg = bid / units;
+  }
+  const int total = (int)p.rows_per_stat * q;
+  const int64_t base_row = (int64_t)sg * p.rows_per_stat;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4 raw[GNU_MAX];
+#pragma unroll
+  for (int k = 0; k < GNU_MAX; ++k) {
+    const int id = threadIdx.x + k * 1024;
+    if (id < total) {
+      const int row = id / q, ch = unit * uc + (id - row * q) * 8;
+      const int64_t rr = base_row + row;
+      raw[k] = ld16(ch < p.c1 ? p.x + rr * p.c1 + ch : p.x2 + rr * p.c2 + (ch - p.c1));
+    }
+  }
+  float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+  for (int k = 0; k < GNU_MAX; ++k) {
+    const int id = threadIdx.x + k * 1024;
+    if (id < total) {
+      const int cq = id % q;
+      const int ga = (cq * 8) / cpg, n0 = (ga + 1) * cpg - cq * 8;  // channels of this chunk in group ga (>= 8: all)
+      float f[8];
+      unpack8<DT>(raw[k], f);
+      float lo = 0.f, lo2 = 0.f, hi = 0.f, hi2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < n0) {
+          lo += f[j];
+          lo2 = fmaf(f[j], f[j], lo2);
+        } else {
+          hi += f[j];
+          hi2 = fmaf(f[j], f[j], hi2);
+        }
+      }
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        acc[gi][0] += (ga == gi ? lo : 0.f) + (ga + 1 == gi ? hi : 0.f);
+        acc[gi][1] += (ga == gi ? lo2 : 0.f) + (ga + 1 == gi ? hi2 : 0.f);
+      }
+    }
+  }
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float v = acc[gi][t];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+      if (lane == 0) red[wave][gi][t] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < ug) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      a += (double)red[w][threadIdx.x][0];
+      b += (double)red[w][threadIdx.x][1];
+    }
+    const double cnt = (double)p.rows_per_stat * (double)cpg;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[threadIdx.x][0] = (float)mean;
+    mr[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  if (threadIdx.x < uc) {  // per-channel scale / shift of the unit (register pressure: 20 chunks stay live per thread)
+    const int ch = unit * uc + threadIdx.x, gi = threadIdx.x / cpg;
+    const float scale = mr[gi][1] * p.gamma[ch];
+    sc[threadIdx.x] = scale;
+    sh[threadIdx.x] = p.beta[ch] - mr[gi][0] * scale;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < GNU_MAX; ++k) {
+    const int id = threadIdx.x + k * 1024;
+    if (id < total) {
+      const int row = id / q, cq = id - row * q;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + cq * 8), s1 = *reinterpret_cast<const f32x4*>(sc + cq * 8 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + cq * 8), h1 = *reinterpret_cast<const f32x4*>(sh + cq * 8 + 4);
+      float f[8];
+      unpack8<DT>(raw[k], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = fmaf(f[j], j < 4 ? s0[j & 3] : s1[j & 3], j < 4 ? h0[j & 3] : h1[j & 3]);
+        f[j] = p.act == CA_ACT_SILU ? silu_f(v) : v;
+      }
+      st16(p.y + (base_row + row) * C + unit * uc + cq * 8, pack8<DT>(f));
+    }
+  }
+}
+
+// unit width for k_gn_unit: lcm(cpg, 8) if the launch qualifies, else 0
+inline int gn_unit_channels(const GnParams& p) {
+  static const int env = getenv("CA_GN_FUSED") ? atoi(getenv("CA_GN_FUSED")) : 1;
+  const int C = p.c1 + p.c2, cpg = C / p.groups;
+  if (!env || !p.y || cpg % 8 == 0 || cpg < 8) return 0;  // (cpg >= 8: a 16-byte chunk then touches at most two groups)
+  int uc = cpg;
+  while (uc % 8) uc += cpg;
+  if (uc / cpg > 4 || uc > 128 || C % uc != 0 || (p.c2 != 0 && p.c1 % uc != 0)) return 0;
+  return p.rows_per_stat * (uc >> 3) <= 1024 * GNU_MAX ? uc : 0;
+}
+
 inline bool gn_small_ok(const GnParams& p) {
   static const int env = getenv("CA_GN_FUSED") ? atoi(getenv("CA_GN_FUSED")) : 1;  // 0: always the two-kernel path
   const int C = p.c1 + p.c2, cpg = C / p.groups;
@@ -694,6 +819,14 @@ extern "C" int ca_groupnorm(const ca_groupnorm_args* a, void* stream) {
     const dim3 grid(p.groups, a->images / a->frames_per_stat);
     if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_gn_small<CA_BF16>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_gn_small<CA_F16>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    CA_CHECK_LAUNCH("ca_groupnorm");
+    return CA_OK;
+  }
+  if (const int uc = gn_unit_channels(p)) {
+    const int units = (p.c1 + p.c2) / uc;
+    const dim3 grid(units * (a->images / a->frames_per_stat));
+    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_gn_unit<CA_BF16>), grid, dim3(1024), 0, (hipStream_t)stream, p, uc, units);
+    else hipLaunchKernelGGL((k_gn_unit<CA_F16>), grid, dim3(1024), 0, (hipStream_t)stream, p, uc, units);
     CA_CHECK_LAUNCH("ca_groupnorm");
     return CA_OK;
   }

@@ -238,6 +238,12 @@ GN_CASES = [
     (2, 8, 8, 640, 320, 2, 1, 1e-5),
     (16, 64, 64, 320, 0, 1, 1, 1e-5),
     (8, 32, 32, 320, 0, 8, 1, 1e-5),
+    # one-launch kernels (ca_groupnorm): a block owns 40 channels = 4 / 2 / 1 norm groups of one image
+    (3, 64, 64, 320, 0, 1, 1, 1e-5),
+    (8, 32, 32, 640, 0, 1, 1, 1e-6),
+    (8, 32, 32, 320, 320, 1, 1, 1e-5),
+    (16, 16, 16, 1280, 1280, 1, 0, 1e-5),
+    (3, 24, 24, 1280, 0, 1, 1, 1e-5),
 ]
 
 
