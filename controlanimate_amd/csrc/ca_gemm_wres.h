@@ -208,9 +208,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
           rr[i][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, j * 32, 0));
         }
     }
-    if (!p.ln_colsum && !p.rowbias && p.alpha == 1.f && p.post == 1.f && p.act == CA_ACT_NONE && !p.geglu) {
-      // the common case (projections with bias and residual): ~12 VALU instructions per fragment instead of ~45 --
-      // the epilogue's VALU time is of the order of the slab's MFMA time, and it is the part that does not scale away
+    if (!p.rowbias && p.alpha == 1.f && p.post == 1.f && p.act == CA_ACT_NONE && !p.geglu) {
+      // the common cases (projections with bias, residual and / or a folded LayerNorm): ~12-20 VALU instructions per
+      // fragment instead of ~45 -- the epilogue's VALU time is of the order of the slab's MFMA time, and it is the part
+      // that does not scale away
       unsigned off[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -220,11 +221,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const f32x4 bi = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (j * 16 + g * 4) * 4);
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+        if (p.ln_colsum) cs = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (PN + j * 16 + g * 4) * 4);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+          f32x4 v = acc[i][j];
+          if (p.ln_colsum) {  // rstd * (x W'^T - mean * colsum(W')): same operation order as the general path
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = st[i].y * (v[r] - st[i].x * cs[r]);
+          }
           u32x2 w;
-          w[0] = pack2<DT>(acc[i][j][0] + bi[0], acc[i][j][1] + bi[1]);
-          w[1] = pack2<DT>(acc[i][j][2] + bi[2], acc[i][j][3] + bi[3]);
+          w[0] = pack2<DT>(v[0] + bi[0], v[1] + bi[1]);
+          w[1] = pack2<DT>(v[2] + bi[2], v[3] + bi[3]);
           if (p.res) {
             if (DT == CA_F16) {  // fp16 + fp16 is exact in fp32, so the packed add rounds exactly like the fp32 path
               // (inline asm: hipcc 7.2 miscompiled the ext_vector _Float16 addition here -- the second add reused the
