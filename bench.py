@@ -146,8 +146,8 @@ def tile_name(m: int, n: int, k: int, conv: bool) -> str:
         tiles = cdiv(m, 128) * (n // 320)
         if 128 <= tiles <= 256 or (128 <= tiles <= 512 and not conv):
             return "pp128x320"
-    if (not conv) and n >= 5120 and k >= 640 and n % 128 == 0 and cdiv(m, 256) * (n // 128) >= 512:
-        return "256x128"
+    if os.environ.get("CA_GEMM_BIG") == "3" and (not conv) and n >= 5120 and k >= 640 and n % 128 == 0 and cdiv(m, 256) * (n // 128) >= 512:
+        return "256x128"  # (round-1 default; off since round 2: slower inside the step)
     wide = n % 128 == 0 and cdiv(m, 128) * cdiv(n, 128) >= 512
     if not wide and n % 160 == 0 and cdiv(m, 128) * (n // 160) >= 512:
         return "128x160"

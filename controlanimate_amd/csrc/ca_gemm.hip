@@ -522,7 +522,8 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
                         p.a_bytes < 0x7FFFFF00u && p.w_bytes < 0x7FFFFF00u && (!p.c2 || p.a2_bytes < 0x7FFFFF00u);
     const bool pp3_ok = nt >= 5 && !p.out_f32 && fits32 && (!p.rowbias || p.rows_per_group % 64 == 0) && p.ldc % 8 == 0 && (!p.res || p.ld_res % 8 == 0);
     if (pp3_ok && pp_env == 4) return ca_launch_gemm_pp(p, DT, MODE, 321, (unsigned)tiles, st);
-    if (pp_env == 1 || pp_env == 2 || (pp_env < 0 && tiles >= 128 && nt >= 10 && (tiles <= 256 || (tiles <= 512 && MODE == 0))))
+    // (thresholds re-checked inside the step, same box, interleaved: dense 768 / 1024 tiles +0.25 ms, conv 512 +0.7, conv 128 +0.2)
+    if (p.row_sums || pp_env == 1 || pp_env == 2 || (pp_env < 0 && tiles >= 128 && nt >= 10 && (tiles <= 256 || (tiles <= 512 && MODE == 0))))
       return ca_launch_gemm_pp(p, DT, MODE, 320, (unsigned)tiles, st);
   }
   if (dma && (pp_env == 1 || pp_env == 3) && nt >= 2 && p.n % 128 == 0 && p.splits <= 1) {
@@ -550,10 +551,11 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
     hipLaunchKernelGGL((k_gemm_dma<DT, 128, 160, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
     return CA_OK;
   }
-  // CA_GEMM_BIG: 0 never, 1 whenever the grid allows, unset: the wide feed-forward GEMMs only (measured
-  // +4..8% on 8192x10240x1280 and 32768x5120x640; neutral or negative on K = 320 and on the convolutions)
-  static const int big_env = getenv("CA_GEMM_BIG") ? atoi(getenv("CA_GEMM_BIG")) : -1;
-  const bool big = big_env == 1 || (big_env < 0 && MODE == 0 && p.n >= 5120 && kc >= 640);
+  // CA_GEMM_BIG: 1 = 256x128 tiles whenever the grid allows, 3 = the wide feed-forward GEMMs only (the round-1 default:
+  // +4..8% on 8192x10240x1280 and 32768x5120x640 measured in isolation), unset / 0 = never: inside the step, with the
+  // ControlNet stream beside it, the 128x128 tiles are 0.3 ms faster (67.6 vs 67.9, same box, interleaved runs)
+  static const int big_env = getenv("CA_GEMM_BIG") ? atoi(getenv("CA_GEMM_BIG")) : 0;
+  const bool big = big_env == 1 || (big_env == 3 && MODE == 0 && p.n >= 5120 && kc >= 640);
   if (dma && big_env == 2 && p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 256) * (p.n / 128) >= 256) {
     // experiment: 4 waves x (128 x 64) per wave -- 12 instead of 16 fragment reads per 32 MFMAs, 2 blocks per CU
     const dim3 grid(ceil_div_i(p.m, 256) * (p.n / 128));
