@@ -254,6 +254,36 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
       }
       continue;
     }
+    if (p.geglu && !p.rowbias && !p.res && p.alpha == 1.f && p.post == 1.f && p.act == CA_ACT_NONE) {
+      // the feed-forward projection (folded LayerNorm, bias, GEGLU): the same arithmetic as the general path below
+      // without its per-fragment branches and row-bias / residual / scale steps
+      unsigned off[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + l15;
+        off[i] = m < p.m ? ((unsigned)m * (unsigned)p.ldc + (unsigned)((n0 >> 1) + g * 2)) * 2u : DMA_OOB;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (j * 16 + g * 4) * 4);
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+        if (p.ln_colsum) cs = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (PN + j * 16 + g * 4) * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x4 v = acc[i][j];
+          if (p.ln_colsum) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = st[i].y * (v[r] - st[i].x * cs[r]);
+          }
+          float h[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = Elem<DT>::to_f(Elem<DT>::from_f(v[r] + bi[r]));  // (the Linear's output is rounded first)
+          const f32x2 gg = gelu_erf_f2((f32x2){h[1], h[3]});
+          __builtin_amdgcn_raw_buffer_store_b32(pack2<DT>(h[0] * gg[0], h[2] * gg[1]), rs_c, off[i], j * 16, 0);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nl = j * 16 + g * 4;
