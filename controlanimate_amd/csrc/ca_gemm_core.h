@@ -245,20 +245,62 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
           for (int r = 0; r < 4; ++r) v[r] += b[r];
         }
       }
+      if (p.alpha != 1.f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+      }
       u32x2 o;
-      o[0] = pack2<DT>(v[0] * p.alpha, v[1] * p.alpha);
-      o[1] = pack2<DT>(v[2] * p.alpha, v[3] * p.alpha);
+      o[0] = pack2<DT>(v[0], v[1]);
+      o[1] = pack2<DT>(v[2], v[3]);
       *reinterpret_cast<u32x2*>(cs + row * CLD + col) = o;
     }
   }
   __syncthreads();
   constexpr int CH = BN / 8;
+  const bool simple = p.post == 1.f && p.act == CA_ACT_NONE && !p.geglu && !p.out_f32;
 #pragma unroll
   for (int u = 0; u < BM * CH / NT; ++u) {
     const int id = tid + u * NT;
     const int row = id / CH, c8 = id - row * CH;
     const int m = m0 + row, n = n0 + c8 * 8;
     if (m >= p.m || n >= p.n) continue;
+    if (simple) {
+      // no post scale / activation / GEGLU / fp32 output: the staged value IS the result, or it only takes the residual --
+      // fp16 + fp16 is exact in fp32, so a packed add rounds exactly like the unpack / fp32 add / round of the general
+      // path below (28-40 fewer VALU instructions per 16-byte chunk)
+      u32x4 pk = ld16(cs + row * CLD + c8 * 8);
+      if (p.res) {
+        const u32x4 rr = ld16(p.res + (int64_t)m * p.ld_res + n);
+        if (DT == CA_F16) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            unsigned s_;
+            asm("v_pk_add_f16 %0, %1, %2" : "=v"(s_) : "v"(pk[k]), "v"(rr[k]));  // (inline asm: see ca_gemm_wres.h on the ext-vector miscompile)
+            pk[k] = s_;
+          }
+        } else {
+          float a_[8], r_[8];
+          unpack8<DT>(pk, a_);
+          unpack8<DT>(rr, r_);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a_[k] += r_[k];
+          pk = pack8<DT>(a_);
+        }
+      }
+      st16(reinterpret_cast<u16*>(p.c) + (int64_t)m * p.ldc + n, pk);
+      if (ROWSUM && p.row_sums) {
+        float r[8];
+        unpack8<DT>(pk, r);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          a += r[k];
+          b = fmaf(r[k], r[k], b);
+        }
+        rs[row * CH + c8] = make_float2(a, b);
+      }
+      continue;
+    }
     float v[8];
     unpack8<DT>(ld16(cs + row * CLD + c8 * 8), v);
     if (p.res) {
