@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
           rr[i][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, j * 32, 0));
         }
     }
-    if (!p.rowbias && p.alpha == 1.f && p.post == 1.f && p.act == CA_ACT_NONE && !p.geglu) {
+    if (p.alpha == 1.f && p.post == 1.f && p.act == CA_ACT_NONE && !p.geglu) {
       // the common cases (projections with bias, residual and / or a folded LayerNorm): ~12-20 VALU instructions per
       // fragment instead of ~45 -- the epilogue's VALU time is of the order of the slab's MFMA time, and it is the part
       // that does not scale away
@@ -223,6 +223,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
         const f32x4 bi = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (j * 16 + g * 4) * 4);
         f32x4 cs = {0.f, 0.f, 0.f, 0.f};
         if (p.ln_colsum) cs = *reinterpret_cast<const f32x4*>(smem + OFF_PAR + (PN + j * 16 + g * 4) * 4);
+        f32x4 bb = bi;
+        if (p.rowbias) {  // (the general path adds bias then row bias to the value; here their sum first: last-bit differences only)
+          const f32x4 rb = *reinterpret_cast<const f32x4*>(rb_patch + (j * 16 + g * 4) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bb[r] += rb[r];
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           f32x4 v = acc[i][j];
@@ -231,8 +237,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
             for (int r = 0; r < 4; ++r) v[r] = st[i].y * (v[r] - st[i].x * cs[r]);
           }
           u32x2 w;
-          w[0] = pack2<DT>(v[0] + bi[0], v[1] + bi[1]);
-          w[1] = pack2<DT>(v[2] + bi[2], v[3] + bi[3]);
+          w[0] = pack2<DT>(v[0] + bb[0], v[1] + bb[1]);
+          w[1] = pack2<DT>(v[2] + bb[2], v[3] + bb[3]);
           if (p.res) {
             if (DT == CA_F16) {  // fp16 + fp16 is exact in fp32, so the packed add rounds exactly like the fp32 path
               // (inline asm: hipcc 7.2 miscompiled the ext_vector _Float16 addition here -- the second add reused the
