@@ -258,6 +258,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
   __syncthreads();
   constexpr int CH = BN / 8;
   const bool simple = p.post == 1.f && p.act == CA_ACT_NONE && !p.geglu && !p.out_f32;
+  const bool geglu_only = p.geglu && p.post == 1.f && p.act == CA_ACT_NONE && !p.res && !p.out_f32;
 #pragma unroll
   for (int u = 0; u < BM * CH / NT; ++u) {
     const int id = tid + u * NT;
@@ -299,6 +300,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKParams& p, f32x4 (&acc)
         }
         rs[row * CH + c8] = make_float2(a, b);
       }
+      continue;
+    }
+    if (geglu_only) {  // the feed-forward projection: h * gelu(g) of the staged (rounded) pairs, nothing else
+      float v[8];
+      unpack8<DT>(ld16(cs + row * CLD + c8 * 8), v);
+      const f32x2 g0 = gelu_erf_f2((f32x2){v[1], v[3]}), g1 = gelu_erf_f2((f32x2){v[5], v[7]});
+      u32x2 w;
+      w[0] = pack2<DT>(v[0] * g0[0], v[2] * g0[1]);
+      w[1] = pack2<DT>(v[4] * g1[0], v[6] * g1[1]);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<u16*>(p.c) + (int64_t)m * p.ldc + (n >> 1)) = w;
       continue;
     }
     float v[8];
