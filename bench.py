@@ -558,8 +558,12 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             graph_state["graph"], use_graph = None, False
             torch.cuda.synchronize()
+    # The timed region starts AT a window start (step index 0 of a window): the warm-up steps are the last ones of the
+    # previous window.  K timed steps therefore contain ceil(K / steps_per_window) window starts with their per-window
+    # work (one per 10 steps at the default K = 10: twice the rate of a 20-step window, i.e. never under-counted).
+    i0 = (-args.warmup) % steps_per_window
     for i in range(args.warmup):
-        step(i)
+        step(i0 + i)
     torch.cuda.synchronize()
     barrier()
     timer.enabled = False  # per-launch HIP events cost ~7% of a step: they are taken in a second pass
@@ -568,7 +572,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
-        step(args.warmup + i)
+        step(i0 + args.warmup + i)
         ev[i][1].record()
     torch.cuda.synchronize()
     barrier()
@@ -625,8 +629,9 @@ def main():
         # steady state of the sliding window (scripts/vid2vid.py:168-189): a window re-feeds `overlap_length` frames, so it
         # contributes frame_count - overlap_length NEW frames; equal to `value` when the config has no overlap
         "frames_per_sec_steady_state": round(world * f_new / (steps_per_window * sec_per_step), 4),
+        "window_starts_in_timed_region": (args.steps + steps_per_window - 1) // steps_per_window,
         "per_window_work_in_timed_region": ("hint embedding + text/IP K/V recomputed in place at every window start "
-                                            f"({window_refresh['gemms']} launches groups)" if use_graph else
+                                            f"({window_refresh['gemms']} launches groups); the timed region begins at a window start" if use_graph else
                                             "eager run: nothing is cached outside the timed region except across the steps of a window"),
         "step_algorithmic_tflop": round(step_tflop, 2),
         "step_mfma_frac": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
