@@ -80,19 +80,25 @@ def test_config4_full_size_ip_adapter_two_guess_mode_controlnets():
     eps_again = unet.forward_nhwc(x2, 2, f, 500, prompt_same, down, mid)
     torch.cuda.synchronize()
     assert eps.shape == (2 * f, h, w, 4) and torch.isfinite(eps).all()
-    assert torch.equal(eps, eps_again)                           # deterministic kernels (no atomics)
-    assert torch.equal(eps[:f], eps[f:])                         # identical halves -> identical results, bit for bit
+    def same(a, b, what):  # bit-for-bit, and say how far apart if not (a race shows up as a few scattered elements)
+        if not torch.equal(a, b):
+            d = (a.float() - b.float()).abs()
+            raise AssertionError(f"{what}: {int((d > 0).sum())} of {d.numel()} elements differ, max |d| = {float(d.max()):.3e}, "
+                                 f"first at flat index {int((d.flatten() > 0).nonzero()[0])}")
+    same(eps, eps_again, "two identical forwards")              # deterministic kernels (no atomics)
+    same(eps[:f], eps[f:], "CFG halves with identical conditioning")   # identical halves -> identical results, bit for bit
     assert 0.05 < float(eps.float().std()) < 50
     # broadcast residuals (b = 1) == the same residuals written out for both halves
     down2 = [torch.cat([d, d]) for d in down]
     eps_doubled = unet.forward_nhwc(x2, 2, f, 500, prompt_same, down2, torch.cat([mid, mid]))
     torch.cuda.synchronize()
-    assert torch.equal(eps, eps_doubled)
+    same(eps, eps_doubled, "broadcast vs written-out ControlNet residuals")
     # the image tokens matter on the UNet (IP branch) and are ignored by the ControlNets (CN processor)
     pos_other = pos.clone()
     pos_other[:, 77:] = torch.randn(1, 4, 768, generator=g).to(DEV)
     down_o, mid_o = cn.residuals_nhwc(x2[:f], 500, pos_other, True)
-    assert all(torch.equal(a, b) for a, b in zip(down, down_o)) and torch.equal(mid, mid_o)
+    for k, (a, b) in enumerate(zip(list(down) + [mid], list(down_o) + [mid_o])):
+        same(a, b, f"ControlNet residual {k} with other image tokens")
     eps_o = unet.forward_nhwc(x2, 2, f, 500, torch.cat([pos_other, pos_other]).contiguous(), down, mid)
     assert not torch.equal(eps, eps_o)
 
