@@ -112,20 +112,28 @@ class ControlNetModel(HipModelMixin, nn.Module):
         key = self._hint_key
         if key is not None and key[0] is controlnet_cond and key[1] == controlnet_cond._version and self._hint_emb is not None:
             return self._hint_emb
-        ce = self.controlnet_cond_embedding
-        nhwc = K.ncfhw_to_nhwc(controlnet_cond.to(device).unsqueeze(2), ce.conv_in.cin_pad, self.act_dtype)
-        self._hint_emb = ce(nhwc)
+        self._hint_emb = self._embed_hints(controlnet_cond, device)
         self._hint_key = (controlnet_cond, controlnet_cond._version)
         return self._hint_emb
+
+    def _embed_hints(self, controlnet_cond: torch.Tensor, device) -> torch.Tensor:
+        """The eight-convolution hint embedding (full-resolution 16- and 32-channel layers: the most expensive per-window
+        work).  Hints that `prep_control_images` doubled for classifier-free guidance (`torch.cat([ctrl] * 2)`, reference
+        :268-269) carry `_cfg_doubled`: the two halves are the same images, so one half is embedded and repeated -- the same
+        bits, half the work."""
+        ce = self.controlnet_cond_embedding
+        cond = controlnet_cond
+        doubled = bool(getattr(cond, "_cfg_doubled", False)) and cond.shape[0] % 2 == 0
+        if doubled:
+            cond = cond[: cond.shape[0] // 2]
+        emb = ce(K.ncfhw_to_nhwc(cond.to(device).unsqueeze(2), ce.conv_in.cin_pad, self.act_dtype))
+        return torch.cat([emb, emb]) if doubled else emb
 
     def refresh_window_caches(self) -> int:
         """HipModelMixin.refresh_window_caches + the hint embedding of the current control images (in place)."""
         n = super().refresh_window_caches()
         if self._hint_key is not None and self._hint_emb is not None:
-            ce = self.controlnet_cond_embedding
-            cond = self._hint_key[0]
-            nhwc = K.ncfhw_to_nhwc(cond.to(self._hint_emb.device).unsqueeze(2), ce.conv_in.cin_pad, self.act_dtype)
-            self._hint_emb.copy_(ce(nhwc))
+            self._hint_emb.copy_(self._embed_hints(self._hint_key[0], self._hint_emb.device))
             n += 1
         return n
 

@@ -85,6 +85,7 @@ class MultiControlNetResidualsPipeline:
             ctrl = torch.stack(frames).to(self.device)
             if do_classifier_free_guidance and not guess_mode and not self.use_lcm:
                 ctrl = torch.cat([ctrl] * 2)
+                ctrl._cfg_doubled = True  # (both halves are the same frames: the hint embedding is computed for one)
             prep.append(ctrl)
         self.prep_images = prep
 

@@ -222,3 +222,25 @@ def test_ip_adapter_image_tokens_match_the_reference_projection():
     assert proc.scale == 0.35
     assert tuple(cond.shape) == (1, 4, 768) and rel(cond, torch.from_numpy(fx["tokens"][:1])) < 3e-3
     assert rel(uncond, torch.from_numpy(fx["uncond"][:1])) < 3e-3
+
+
+def test_hint_embedding_of_cfg_doubled_hints_is_computed_once():
+    """`prep_control_images` doubles the control frames for classifier-free guidance (reference :268-269); the two halves
+    are the same images, so the eight-convolution hint embedding runs on one half and is repeated: the same bits as
+    embedding the doubled batch, half of the most expensive per-window work."""
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    net = _full_controlnet(21, strip_ip=False)
+    g = torch.Generator().manual_seed(9)
+    frames = torch.rand(4, 3, 128, 192, generator=g)
+    cn = MultiControlNetResidualsPipeline(["a"], [1.0], use_lcm=False, controlnets=[net], device=DEV)
+    cn.prep_control_images([x for x in frames], do_classifier_free_guidance=True, guess_mode=False)
+    doubled = cn.prep_images[0]
+    assert doubled.shape[0] == 8 and getattr(doubled, "_cfg_doubled", False)
+    once = net.hint_embedding(doubled, DEV).clone()
+    plain = doubled.clone()                       # the same values without the marker: embedded as 8 independent images
+    assert not getattr(plain, "_cfg_doubled", False)
+    full = net.hint_embedding(plain, DEV)
+    torch.cuda.synchronize()
+    assert once.shape == full.shape == (8, 16, 24, 320) and torch.equal(once, full) and torch.equal(once[:4], once[4:])
+    cn.prep_control_images([x for x in frames], do_classifier_free_guidance=True, guess_mode=True)
+    assert cn.prep_images[0].shape[0] == 4 and not getattr(cn.prep_images[0], "_cfg_doubled", False)
