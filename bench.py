@@ -512,11 +512,12 @@ def main():
         down = mid = None
         if cn is not None:
             x_cn = x_static[:f] if (cn_single and rep == 2) else x_static
+            twice = rep == 2 and not cn_single  # (as ControlAnimationPipeline.__call__: x_static repeats one latent tensor)
             if overlap["on"]:  # ControlNet beside the UNet encoder on a second stream (as the pipeline does)
-                down = cn.residuals_nhwc_async(x_cn, t, cn_prompt, wl["guess_mode"])
+                down = cn.residuals_nhwc_async(x_cn, t, cn_prompt, wl["guess_mode"], cfg_identical_halves=twice)
             else:
-                down, mid = cn.residuals_nhwc(x_cn, t, cn_prompt, wl["guess_mode"])
-        return unet.forward_nhwc(x_static, rep, f, t, prompt, down, mid)
+                down, mid = cn.residuals_nhwc(x_cn, t, cn_prompt, wl["guess_mode"], cfg_identical_halves=twice)
+        return unet.forward_nhwc(x_static, rep, f, t, prompt, down, mid, cfg_identical_halves=rep == 2)
 
     def step(i):
         idx = i % steps_per_window
@@ -612,6 +613,11 @@ def main():
     # per ControlNet: the reference feeds it b*f images, or f in guess mode / without CFG
     cn_tflop = wl["cn_tflop"] * scale
     step_tflop = wl["unet_tflop"] * scale + len(nets) * cn_tflop
+    shared_tflop = 0.0
+    if rep == 2 and os.environ.get("CA_CFG_SHARED", "1") != "0":
+        rows_half, n_tok = f * (wl["height"] // 8) * (wl["width"] // 8), (wl["height"] // 8) * (wl["width"] // 8)
+        one = (2 * 2.0 * rows_half * 320 * 2880 + 2.0 * rows_half * 320 * 1600 + 4.0 * n_tok * n_tok * 320 * f) * 1e-12
+        shared_tflop = one * (1 + (0 if cn_single else len(nets)))  # UNet + every ControlNet that sees both halves
     f_new = f - wl["overlap"]
     out = {
         "metric": "frames_per_sec", "value": round(fps, 4), "unit": "frames/s",
@@ -635,6 +641,12 @@ def main():
                                             "eager run: nothing is cached outside the timed region except across the steps of a window"),
         "step_algorithmic_tflop": round(step_tflop, 2),
         "step_mfma_frac": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
+        # classifier-free guidance repeats ONE latent tensor for both batch halves: up to the first cross-attention (conv_in,
+        # first resnet, first transformer's GroupNorm / proj_in / 4096-token self-attention) the halves are the same
+        # computation, which runs once (bit-identical results: tests/test_configs_gpu.py; CA_CFG_SHARED=0 disables).  The
+        # algorithmic count above is the reference's, which computes both halves; this is what was executed.
+        "cfg_shared_prefix": bool(shared_tflop > 0),
+        "step_executed_tflop": round(step_tflop - shared_tflop, 2),
         "vae": None if vae_ms is None else {
             **vae_ms,
             "frames_per_sec_end_to_end": round(world * f / (steps_per_window * sec_per_step + 1e-3 * (vae_ms["encode_ms_per_window"] + vae_ms["decode_ms_per_window"])), 4),

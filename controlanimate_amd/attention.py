@@ -106,6 +106,11 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
         """x: [images, tokens, C]."""
+        return self.forward_rest(self.forward_self(x), ctx)
+
+    def forward_self(self, x: torch.Tensor) -> torch.Tensor:
+        """norm1 + self-attention + residual: the part that does not see the prompt (UNet3DConditionModel.forward_nhwc
+        runs it once for the two identical halves of a classifier-free-guidance batch)."""
         B, N, C = x.shape
         # (each projection that feeds a folded LayerNorm is asked for the row sums of its output: K.gemm(row_sums=True))
         next_folded = (self.attn2.fold if self.attn2 is not None else self.ff.fold) is not None
@@ -114,6 +119,11 @@ class BasicTransformerBlock(nn.Module):
                            row_sums=next_folded)
         else:
             x = self.attn1(self.norm1.run(x.view(B * N, C)).view(B, N, C), residual=x, row_sums=next_folded)
+        return x
+
+    def forward_rest(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
+        """norm2 + cross-attention, norm3 + feed-forward (with their residuals)."""
+        B, N, C = x.shape
         if self.attn2 is not None:
             kw = dict(encoder_hidden_states=ctx.ehs, residual=x, frames_per_kv=ctx.frames_per_kv, kv_mod=ctx.kv_mod, cache=ctx.cache,
                       row_sums=self.ff.fold is not None)
@@ -150,12 +160,21 @@ class Transformer3DModel(nn.Module):
             b.pack(arena, dtype)
         self.proj_out.pack(arena, dtype)
 
-    def forward(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, ctx: ExecCtx, shared_half: bool = False) -> torch.Tensor:
+        """shared_half: `x` holds ONE of the two identical halves of a classifier-free-guidance batch (ctx describes the
+        full batch): GroupNorm, proj_in and the first block's self-attention run once, then the activations are repeated
+        and the prompt-dependent rest runs on the full batch.  Identical inputs give identical outputs, so the result is
+        what the full-batch path computes."""
         images, h, w, c = x.shape
         rows = images * h * w
         y = self.norm.run(x)  # always per image (reference rearranges to (b f) first, attention.py:124)
         y0 = self.proj_in.run(y.view(rows, c), row_sums=self.transformer_blocks[0].attn1.fold is not None)
         y = K.carry_row_sums(y0.view(images, h * w, -1), y0)
-        for blk in self.transformer_blocks:
+        if shared_half:
+            y = self.transformer_blocks[0].forward_self(y)
+            y, x = torch.cat([y, y]), torch.cat([x, x])
+            images, rows = 2 * images, 2 * rows
+            y = self.transformer_blocks[0].forward_rest(y, ctx)
+        for blk in (self.transformer_blocks[1:] if shared_half else self.transformer_blocks):
             y = blk(y, ctx)
         return self.proj_out.run(y.view(rows, -1), residual=x.view(rows, c)).view(images, h, w, c)

@@ -318,11 +318,13 @@ class ControlAnimationPipeline:
             down = mid = None
             if cn is not None:
                 x_cn = x if (rep == 1 or not cn_single) else x[:f]
+                twice = rep == 2 and not cn_single  # the ControlNet sees both (identical) CFG halves of the latents
                 if getattr(self, "overlap_controlnet", True):
-                    down = cn.residuals_nhwc_async(x_cn, tt, cn_prompt, guess_mode)  # joined inside the UNet
+                    down = cn.residuals_nhwc_async(x_cn, tt, cn_prompt, guess_mode, cfg_identical_halves=twice)  # joined inside the UNet
                 else:
-                    down, mid = cn.residuals_nhwc(x_cn, tt, cn_prompt, guess_mode)
-            return unet.forward_nhwc(x, rep, f, tt, unet_prompt, down, mid, timestep_cond=w_embedding)
+                    down, mid = cn.residuals_nhwc(x_cn, tt, cn_prompt, guess_mode, cfg_identical_halves=twice)
+            # x = latents_to_nhwc(latents, rep): for rep == 2 the two CFG halves are the same tensor (reference :797)
+            return unet.forward_nhwc(x, rep, f, tt, unet_prompt, down, mid, timestep_cond=w_embedding, cfg_identical_halves=rep == 2)
 
         for i, t in enumerate(timesteps):
             idx = first + i

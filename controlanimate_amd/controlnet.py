@@ -15,6 +15,8 @@ same NHWC kernels as the UNet.  Fusions:
 """
 from __future__ import annotations
 
+import dataclasses
+
 from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -150,7 +152,7 @@ class ControlNetModel(HipModelMixin, nn.Module):
     @torch.no_grad()
     def forward_nhwc(self, x: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
                      conditioning_scale: float = 1.0, guess_mode: bool = False,
-                     accumulate: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None):
+                     accumulate: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None, cfg_identical_halves: bool = False):
         """x: [B,h,w,cin_pad] activation dtype. Returns (12 NHWC residuals, mid), already scaled and --
         if `accumulate` holds the running sums of previous nets -- added to them."""
         device = x.device
@@ -164,9 +166,22 @@ class ControlNetModel(HipModelMixin, nn.Module):
         hint = self.hint_embedding(controlnet_cond, device)
         if hint.shape[0] != images:
             raise ValueError(f"controlnet_cond batch {hint.shape[0]} != sample batch {images}")
-        x = self.conv_in.run(x, residual=hint)
-        outs = [x]
-        for blk in self.down_blocks:
+        # CFG-doubled input (the caller repeated one latent tensor, `cfg_identical_halves`) with CFG-doubled hints: the two
+        # halves are identical up to the first cross-attention -- see UNet3DConditionModel.forward_nhwc
+        first = self.down_blocks[0]
+        from .unet import _CFG_SHARED_ON
+        shared = (cfg_identical_halves and _CFG_SHARED_ON and images % 2 == 0 and bool(getattr(controlnet_cond, "_cfg_doubled", False)) and
+                  getattr(first, "has_cross_attention", False) and (not torch.is_tensor(timestep) or timestep.numel() == 1))
+        if shared:
+            half = images // 2
+            xh = self.conv_in.run(x[:half], residual=hint[:half])
+            outs = [torch.cat([xh, xh])]
+            x, o = first(xh, ctx, half_ctx=dataclasses.replace(ctx, b=half))
+            outs += o
+        else:
+            x = self.conv_in.run(x, residual=hint)
+            outs = [x]
+        for blk in (self.down_blocks[1:] if shared else self.down_blocks):
             x, o = blk(x, ctx)
             outs += o
         x = self.mid_block(x, ctx)
@@ -215,10 +230,11 @@ class MultiControlNetModel(nn.Module):
         return self
 
     def forward_nhwc(self, x, timestep, encoder_hidden_states, controlnet_cond: Sequence[torch.Tensor],
-                     conditioning_scale: Sequence[float], guess_mode: bool = False):
+                     conditioning_scale: Sequence[float], guess_mode: bool = False, cfg_identical_halves: bool = False):
         acc = None
         for net, cond, scale in zip(self.nets, controlnet_cond, conditioning_scale):
-            acc = net.forward_nhwc(x, timestep, encoder_hidden_states, cond, scale, guess_mode, accumulate=acc)
+            acc = net.forward_nhwc(x, timestep, encoder_hidden_states, cond, scale, guess_mode, accumulate=acc,
+                                   cfg_identical_halves=cfg_identical_halves)
         return acc
 
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, class_labels=None,

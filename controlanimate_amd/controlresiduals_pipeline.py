@@ -90,13 +90,17 @@ class MultiControlNetResidualsPipeline:
         self.prep_images = prep
 
     # ------------------------------------------------------------------------------------------
-    def residuals_nhwc(self, x_nhwc: torch.Tensor, t, controlnet_prompt_embeds: torch.Tensor, guess_mode: bool):
-        """x_nhwc: [(b f),h,w,8] -> (12 NHWC residuals, mid), summed over the nets."""
+    def residuals_nhwc(self, x_nhwc: torch.Tensor, t, controlnet_prompt_embeds: torch.Tensor, guess_mode: bool,
+                       cfg_identical_halves: bool = False):
+        """x_nhwc: [(b f),h,w,8] -> (12 NHWC residuals, mid), summed over the nets.  cfg_identical_halves: x_nhwc is one
+        latent tensor repeated for the two CFG halves (see UNet3DConditionModel.forward_nhwc)."""
         if self.prep_images is None:
             raise RuntimeError("call prep_control_images() first")
-        return self.controlnet.forward_nhwc(x_nhwc, t, controlnet_prompt_embeds, self.prep_images, self.cond_scale, guess_mode)
+        return self.controlnet.forward_nhwc(x_nhwc, t, controlnet_prompt_embeds, self.prep_images, self.cond_scale, guess_mode,
+                                            cfg_identical_halves=cfg_identical_halves)
 
-    def residuals_nhwc_async(self, x_nhwc: torch.Tensor, t, controlnet_prompt_embeds: torch.Tensor, guess_mode: bool):
+    def residuals_nhwc_async(self, x_nhwc: torch.Tensor, t, controlnet_prompt_embeds: torch.Tensor, guess_mode: bool,
+                             cfg_identical_halves: bool = False):
         """Same as residuals_nhwc, but enqueued on a second HIP stream so the ControlNet stack runs beside
         the UNet encoder (they are independent until the residual adds, unet.py:567-586): the kernels of
         one fill the CUs the other leaves idle in its launch tails and small-grid levels.  Returns
@@ -112,7 +116,7 @@ class MultiControlNetResidualsPipeline:
         capturing = torch.cuda.is_current_stream_capturing()
         side.wait_stream(main)  # x_nhwc (and on the first call the weights) were produced on `main`
         with torch.cuda.stream(side):
-            down, mid = self.residuals_nhwc(x_nhwc, t, controlnet_prompt_embeds, guess_mode)
+            down, mid = self.residuals_nhwc(x_nhwc, t, controlnet_prompt_embeds, guess_mode, cfg_identical_halves)
             done = side.record_event()
         if not capturing:
             x_nhwc.record_stream(side)

@@ -15,6 +15,7 @@ same forward signature and output type.  What is different is everything underne
 """
 from __future__ import annotations
 
+import dataclasses
 import json
 import os
 from dataclasses import dataclass
@@ -63,6 +64,9 @@ class TimestepEmbedding(nn.Module):
         self.linear_2.pack(arena, dtype)
         if self.cond_proj is not None:
             self.cond_proj.pack(arena, dtype)
+
+
+_CFG_SHARED_ON = os.environ.get("CA_CFG_SHARED", "1") != "0"  # (0: both CFG halves all the way -- A/B runs)
 
 
 class HipModelMixin:
@@ -362,11 +366,15 @@ class UNet3DConditionModel(HipModelMixin, nn.Module):
 
     @torch.no_grad()
     def forward_nhwc(self, x: torch.Tensor, b: int, f: int, timestep, encoder_hidden_states: torch.Tensor,
-                     down_residuals=None, mid_residual=None, timestep_cond=None) -> torch.Tensor:
+                     down_residuals=None, mid_residual=None, timestep_cond=None, cfg_identical_halves: bool = False) -> torch.Tensor:
         """The whole forward on channels-last tensors (what the denoising loop calls directly).
         x: [b*f, h, w, cin_pad] activation dtype; residuals: NHWC with b*f or f images (broadcast over b),
         or a callable returning (down, mid) that is invoked after the encoder (ControlNet on a 2nd stream);
-        returns eps [b*f, h, w, out_channels] fp32."""
+        returns eps [b*f, h, w, out_channels] fp32.
+        cfg_identical_halves: the caller built `x` by repeating ONE latent tensor for the two classifier-free-guidance
+        halves (`latents_to_nhwc(..., rep=2)`, reference :797) and passes one timestep for both: everything up to the first
+        cross-attention -- conv_in, the first resnet, the first transformer's GroupNorm / proj_in / self-attention (the
+        4096-token one) -- is then the same computation twice and runs once (`CA_CFG_SHARED=0` disables)."""
         device = x.device
         self._ensure_ready(device)
         _, h, w, _ = x.shape
@@ -378,9 +386,19 @@ class UNet3DConditionModel(HipModelMixin, nn.Module):
         temb = self._time_embedding(timestep, b, device, timestep_cond)
         ctx = ExecCtx(b=b, f=f, dtype=self.act_dtype, temb=temb, emb_groups=b, ehs=ehs, frames_per_kv=f,
                       gn_frames_per_stat=1 if self.config.use_inflated_groupnorm else f, cache=cache)
-        x = self.conv_in.run(x)
-        skips = [x]
-        for blk in self.down_blocks:
+        first = self.down_blocks[0]
+        shared = (cfg_identical_halves and _CFG_SHARED_ON and b == 2 and getattr(first, "has_cross_attention", False) and
+                  (not torch.is_tensor(timestep) or timestep.numel() == 1) and (timestep_cond is None or timestep_cond.shape[0] == 1))
+        if shared:
+            half_ctx = dataclasses.replace(ctx, b=1, temb=temb[:1], emb_groups=1)
+            xh = self.conv_in.run(x[: x.shape[0] // 2])
+            skips = [torch.cat([xh, xh])]
+            x, outs = first(xh, ctx, half_ctx=half_ctx)
+            skips += outs
+        else:
+            x = self.conv_in.run(x)
+            skips = [x]
+        for blk in (self.down_blocks[1:] if shared else self.down_blocks):
             x, outs = blk(x, ctx)
             skips += outs
         if callable(down_residuals):  # MultiControlNetResidualsPipeline.residuals_nhwc_async: join the side stream

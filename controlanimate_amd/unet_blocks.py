@@ -61,11 +61,15 @@ class CrossAttnDownBlock3D(_Block):
                                              for _ in range(num_layers)])
         self.downsamplers = nn.ModuleList([Downsample3D(out_channels, use_conv=True, out_channels=out_channels)]) if add_downsample else None
 
-    def forward(self, x: torch.Tensor, ctx: ExecCtx) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    def forward(self, x: torch.Tensor, ctx: ExecCtx, half_ctx: Optional[ExecCtx] = None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+        """half_ctx: `x` is one of the two identical CFG halves (see Transformer3DModel.forward): the first resnet and the
+        prompt-independent head of the first transformer run on it, everything after on the full batch."""
         outs = []
-        for resnet, attn, mm in zip(self.resnets, self.attentions, self.motion_modules):
-            x = resnet(x, ctx)
-            x = attn(x, ctx)
+        for i, (resnet, attn, mm) in enumerate(zip(self.resnets, self.attentions, self.motion_modules)):
+            if i == 0 and half_ctx is not None:
+                x = attn(resnet(x, half_ctx), ctx, shared_half=True)
+            else:
+                x = attn(resnet(x, ctx), ctx)
             if mm is not None:
                 x = mm(x, ctx)
             outs.append(x)

@@ -244,3 +244,31 @@ def test_hint_embedding_of_cfg_doubled_hints_is_computed_once():
     assert once.shape == full.shape == (8, 16, 24, 320) and torch.equal(once, full) and torch.equal(once[:4], once[4:])
     cn.prep_control_images([x for x in frames], do_classifier_free_guidance=True, guess_mode=True)
     assert cn.prep_images[0].shape[0] == 4 and not getattr(cn.prep_images[0], "_cfg_doubled", False)
+
+
+def test_shared_prefix_of_the_two_cfg_halves_changes_nothing():
+    """Classifier-free guidance feeds the SAME latents to both batch halves (reference :797): conv_in, the first resnet and
+    the first transformer's GroupNorm / proj_in / self-attention see identical data twice.  `cfg_identical_halves=True` runs
+    them once and repeats the activations; eps and the ControlNet residuals must be what the full-batch path computes."""
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    f, h, w = 4, 64, 64
+    unet = _full_unet()
+    net = _full_controlnet(31, strip_ip=False)
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(1, 4, f, h, w, generator=g).to(DEV)
+    neg, pos = ((torch.randn(1, 77, 768, generator=g) * 0.5).to(DEV) for _ in range(2))
+    prompt = torch.cat([neg, pos]).contiguous()
+    x2 = K.latents_to_nhwc(lat, unet.conv_in.cin_pad, 2, 1.0, torch.float16)
+    cn = MultiControlNetResidualsPipeline(["a"], [0.8], use_lcm=False, controlnets=[net], device=DEV)
+    cn.prep_control_images([x for x in torch.rand(f, 3, 8 * h, 8 * w, generator=g)], do_classifier_free_guidance=True, guess_mode=False)
+    d_full, m_full = cn.residuals_nhwc(x2, 500, prompt, False)
+    d_full, m_full = [d.clone() for d in d_full], m_full.clone()
+    d_sh, m_sh = cn.residuals_nhwc(x2, 500, prompt, False, cfg_identical_halves=True)
+    for k, (a, b) in enumerate(zip(d_full + [m_full], list(d_sh) + [m_sh])):
+        assert torch.equal(a, b), f"ControlNet residual {k}"
+    eps_full = unet.forward_nhwc(x2, 2, f, 500, prompt, d_full, m_full)
+    eps_sh = unet.forward_nhwc(x2, 2, f, 500, prompt, d_full, m_full, cfg_identical_halves=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eps_sh).all() and torch.equal(eps_full, eps_sh)
+    assert not torch.equal(eps_sh[:f], eps_sh[f:])   # (the halves do differ: different prompts)
