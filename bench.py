@@ -643,7 +643,7 @@ def main():
         "step_mfma_frac": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
         # classifier-free guidance repeats ONE latent tensor for both batch halves: up to the first cross-attention (conv_in,
         # first resnet, first transformer's GroupNorm / proj_in / 4096-token self-attention) the halves are the same
-        # computation, which runs once (bit-identical results: tests/test_configs_gpu.py; CA_CFG_SHARED=0 disables).  The
+        # computation, which runs once (bit-identical results: tests/test_workload_configs_gpu.py; CA_CFG_SHARED=0 disables).  The
         # algorithmic count above is the reference's, which computes both halves; this is what was executed.
         "cfg_shared_prefix": bool(shared_tflop > 0),
         "step_executed_tflop": round(step_tflop - shared_tflop, 2),

@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
-from test_configs_gpu import _full_unet, DEV
+from test_workload_configs_gpu import _full_unet, DEV
 from controlanimate_amd import kernels as K
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 f, h, w = 16, 64, 96
