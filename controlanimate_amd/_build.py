@@ -1,9 +1,13 @@
 """Builds the gfx950 shared library with hipcc (in-tree, no JIT cache).
 
-    python -m controlanimate_amd._build [--force]
+    python -m controlanimate_amd._build [--force] [--experiments]
 
 The library is `controlanimate_amd/csrc/libcontrolanimate_hip.so`; it is git-ignored but
 travels to the GPU box with the repo snapshot.
+
+`--experiments` builds a SECOND library, `csrc/libcontrolanimate_hip_exp.so`, with -DCA_EXPERIMENTS: the same ABI plus
+the tuning environment variables (CA_KNOB in ca_common.h) and the kernels that never became defaults
+(ca_gemm_pp.h, ca_gemm_pp3.h).  It is loaded through CA_HIP_LIB for same-box A/B timing and is never the product path.
 """
 from __future__ import annotations
 
@@ -45,17 +49,24 @@ def _stale(out: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+LIB_EXP = os.path.join(CSRC, "libcontrolanimate_hip_exp.so")
+
+
+def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
     hipcc = _hipcc()
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     jobs = []
     objs = []
+    objdir = os.path.join(CSRC, "build_exp") if experiments else CSRC
+    os.makedirs(objdir, exist_ok=True)
+    lib = LIB_EXP if experiments else LIB
+    xflags = ["-DCA_EXPERIMENTS"] if experiments else []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, *EXTRA.get(s, []), *_extra_env_flags(), "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *xflags, *EXTRA.get(s, []), *_extra_env_flags(), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -68,10 +79,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CA_HIP_LIB") or os.path.join(_HERE, "csrc", "libcontr
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class CAHipUnavailable(RuntimeError):
@@ -97,6 +97,8 @@ SYMBOLS = {
     "ca_gemm_ln_inline_supported": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_gemm_workspace_bytes": (C.c_int64, [C.POINTER(GemmArgs)]),
     "ca_gemm_row_sums_parts": (C.c_int, [C.POINTER(GemmArgs)]),
+    "ca_gemm_plan_name": (C.c_int, [C.POINTER(GemmArgs), C.c_char_p, C.c_int32]),
+    "ca_conv3x3_plan_name": (C.c_int, [C.POINTER(ConvArgs), C.c_char_p, C.c_int32]),
     "ca_conv3x3": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "ca_conv3x3_workspace_bytes": (C.c_int64, [C.POINTER(ConvArgs)]),
     "ca_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_float, C.c_int32, C.c_void_p]),

@@ -679,23 +679,23 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
     hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 1, 32, false>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
   } else {
     // register prefetch of the next K/V tile only where the staging registers fit (head_dim <= 96)
-    static const int pf_env = getenv("CA_ATTN_PF") ? atoi(getenv("CA_ATTN_PF")) : 1;  // tuning knob
+    static const int pf_env = CA_KNOB("CA_ATTN_PF", 1);  // tuning knob
     p.qblocks = ceil_div_i(p.nq, 128);
     const dim3 grid((unsigned)(p.qblocks * p.batches * p.heads));
-    static const int dma_env = getenv("CA_ATTN_DMA") ? atoi(getenv("CA_ATTN_DMA")) : 1;
+    static const int dma_env = CA_KNOB("CA_ATTN_DMA", 1);
     if (DK32 <= 2 && dma_env && !p.causal && p.nk >= 256 && p.k_row % 8 == 0 &&
         ((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2 < (int64_t)0xFFFFFF00ll) {
       // the ones column needs a free, 16-byte aligned pad chunk inside the last 16-wide dv tile
-      static const int sr_env = getenv("CA_ATTN_SR") ? atoi(getenv("CA_ATTN_SR")) : 1;
+      static const int sr_env = CA_KNOB("CA_ATTN_SR", 1);
       const bool sr = sr_env && p.head_dim % 8 == 0 && p.head_dim / 16 == DV16 - 1;
-      static const int fold_env = getenv("CA_ATTN_FOLD") ? atoi(getenv("CA_ATTN_FOLD")) : 1;
+      static const int fold_env = CA_KNOB("CA_ATTN_FOLD", 1);
       const bool fold = sr && fold_env && p.head_dim + 8 <= DK32 * 32;
       if (fold) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, true>), grid, dim3(256), 0, st, p);
       else if (sr) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, false>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, false, false>), grid, dim3(256), 0, st, p);
       return;
     }
-    static const int var_env = getenv("CA_ATTN_VAR") ? atoi(getenv("CA_ATTN_VAR")) : 0;  // experiments (d <= 48 only)
+    static const int var_env = CA_KNOB("CA_ATTN_VAR", 0);  // experiments (d <= 48 only)
     if (DK32 == 2 && DV16 == 3 && var_env == 1) {  // KB = 128
       hipLaunchKernelGGL((k_attn<DT, 2, 3, 2, 4, 128, true>), grid, dim3(256), 0, st, p);
     } else if (DK32 == 2 && DV16 == 3 && var_env == 2) {  // 8 waves, 256 queries per block

@@ -6,6 +6,17 @@
 #include <stdarg.h>
 #include "../../include/controlanimate_hip.h"
 
+// Tuning knobs.  The product build has none: CA_KNOB(name, default) IS its default, so which kernel a call runs is a
+// pure function of its arguments (ca_gemm_plan_name; tests/test_dispatch_plan.py).  Experiment builds (-DCA_EXPERIMENTS:
+// `python -m controlanimate_amd._build --experiments`, loaded through CA_HIP_LIB for same-box A/B timing) read the
+// environment variable once per process.
+#include <stdlib.h>
+#ifdef CA_EXPERIMENTS
+#define CA_KNOB(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define CA_KNOB(name, dflt) (dflt)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

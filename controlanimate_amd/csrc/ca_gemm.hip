@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmKParams p) {
 // Split-K plan for a launch: 1 = none.  Only grids that leave the chip under-filled (8x8 / 16x16 latent
 // levels) and have a long K loop are split; the tile shape used with a split is 128x128 (N % 128 == 0).
 inline int splitk_plan(int m, int n, int nt, int geglu) {
-  static const int env = getenv("CA_SPLITK") ? atoi(getenv("CA_SPLITK")) : -1;
+  static const int env = CA_KNOB("CA_SPLITK", -1);
   if (env == 0 || geglu || n % 128 != 0) return 1;
   const int64_t blocks = (int64_t)ceil_div_i(m, 128) * (n / 128);
   if (blocks >= 384 || nt < 48) return 1;
@@ -436,23 +436,23 @@ inline int splitk_plan(int m, int n, int nt, int geglu) {
 }
 
 // Weight-resident streaming kernel (ca_gemm_wres.h) for the K = 320 GEMMs of the 64x64-latent level: does this dense
-// launch take it?  CA_GEMM_WRES: unset = on when M >= 16384 (measured: a tie at 32768 rows, ahead above), 0 = never,
-// 1 = whenever the shape qualifies.  (Also the condition under which ca_gemm can compute folded-LayerNorm statistics
-// itself: ca_gemm_ln_inline_supported.)
+// launch take it?  M >= 16384 (measured: a tie at 32768 rows, ahead above).  (Also the condition under which ca_gemm can
+// compute folded-LayerNorm statistics itself: ca_gemm_ln_inline_supported.)  The kernel reads ln_stats as (mean, rstd)
+// per row: a launch that hands over partial sums (ln_parts) is not eligible.
 inline bool wres_eligible(const GemmKParams& p) {
-  static const int wres_env = getenv("CA_GEMM_WRES") ? atoi(getenv("CA_GEMM_WRES")) : -1;
+  static const int wres_env = CA_KNOB("CA_GEMM_WRES", -1);  // (experiment builds: 0 = never, 1 = whenever the shape qualifies)
   const int kc = p.c1 + p.c2;
   return wres_env != 0 && kc == 320 && p.taps == 1 && (p.c2 == 0 || p.c1 % 32 == 0) && p.n % 160 == 0 && p.n / 160 <= 32 && !p.out_f32 &&
-         p.splits <= 1 && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0) && p.a_bytes < 0x7FFFFF00u &&
+         p.splits <= 1 && !p.ln_parts && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0) && p.a_bytes < 0x7FFFFF00u &&
          (!p.c2 || p.a2_bytes < 0x7FFFFF00u) && (!p.rowbias || p.rows_per_group % 32 == 0) &&
          (((int64_t)p.m - 1) * p.ldc + (p.geglu ? p.n / 2 : p.n)) * 2 < 0x7FFFFF00ll && (!p.res || (((int64_t)p.m - 1) * p.ld_res + p.n) * 2 < 0x7FFFFF00ll) &&
          (wres_env == 1 || p.m >= 16384);
 }
 
 // Dense GEMMs of the 8x8-latent level (M = 2048: 160 tiles of 128x128 for 256 CUs, each walking its 20..80 K tiles
-// alone at one DMA round trip per tile): the same slab schedule as the small convolutions.  CA_SPLITK_DENSE=0 disables.
+// alone at one DMA round trip per tile): the same slab schedule as the small convolutions.
 inline int splitk_plan_dense(int m, int n, int nt, int geglu, int out_f32) {
-  static const int env = getenv("CA_SPLITK_DENSE") ? atoi(getenv("CA_SPLITK_DENSE")) : -1;
+  static const int env = CA_KNOB("CA_SPLITK_DENSE", -1);
   if (env == 0 || geglu || out_f32 || n % 128 != 0) return 1;
   const int64_t blocks = (int64_t)ceil_div_i(m, 128) * (n / 128);
   // (measured: 2048x1280x5120, 80 K tiles: 55 vs 61 us; 2048x1280x1280, 20 K tiles: 34 vs 19 us -- the fp32 slabs and the
@@ -464,75 +464,108 @@ inline int splitk_plan_dense(int m, int n, int nt, int geglu, int out_f32) {
   return s;
 }
 
-// Dense launches the heuristic below sends to the 128 x 320 ping-pong kernel (whose epilogue can leave per-row sums of
-// its output: ca_gemm_args.row_sums_out).  Same conditions as in launch_gemm.
-inline bool pp2_default_dense(const GemmKParams& p) {
-  static const int pp_env = getenv("CA_GEMM_PP") ? atoi(getenv("CA_GEMM_PP")) : -1;
+// ---- the launch plan: WHICH kernel instantiation a set of arguments runs, as a pure function of the arguments (the
+// product build has no environment knobs: CA_KNOB compiles to its default; experiment builds, -DCA_EXPERIMENTS, read
+// them for same-box A/B runs).  ca_gemm_plan_name / ca_conv3x3_plan_name report it without a launch;
+// tests/test_dispatch_plan.py pins every shape of the benchmark workload to its label.
+enum PlanKind {
+  PK_WRES = 0,    // weight-resident streaming kernel, 160-column panels (ca_gemm_wres.h)
+  PK_PP2,         // 128 x 320 ping-pong tiles (ca_gemm_pp2.h)
+  PK_PP2_SPLITK,  // the same with K ranges writing fp32 slabs + k_splitk_reduce
+  PK_DMA,         // k_gemm_dma<bm, bn>: LDS-DMA staging, nbuf LDS stages
+  PK_DMA_SPLITK,  // k_gemm_dma<128,128> K ranges + k_splitk_reduce
+  PK_REG,         // k_gemm<bm, bn>: register-staged (channel counts the DMA path cannot take)
+  PK_EXP,         // experiment builds only: `exp` selects (see launch_gemm)
+};
+struct GemmPlan {
+  int kind;
+  int bm, bn, waves_m, waves_n, nbuf;
+  int splits;       // K ranges (PK_*_SPLITK)
+  unsigned tiles;   // output tiles (x splits = blocks) of the ping-pong kernels
+  int exp;
+};
+
+inline bool dma_capable(const GemmKParams& p) {
   const int kc = p.c1 + p.c2;
-  const bool dma = kc % BK == 0 && (p.c2 == 0 || p.c1 % BK == 0) && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0);
-  if (!dma || p.taps != 1 || p.splits > 1 || wres_eligible(p) || p.n % 320 != 0 || p.kc_tiles < 2 || (pp_env != -1 && pp_env != 2)) return false;
+  return kc % BK == 0 && (p.c2 == 0 || p.c1 % BK == 0) && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0);
+}
+
+// Dense launches the plan sends to the 128 x 320 ping-pong kernel whatever else is asked (whose epilogue can leave
+// per-row sums of its output: ca_gemm_args.row_sums_out).
+inline bool pp2_default_dense(const GemmKParams& p) {
+  static const int pp_env = CA_KNOB("CA_GEMM_PP", -1);
+  if (!dma_capable(p) || p.taps != 1 || p.splits > 1 || wres_eligible(p) || p.n % 320 != 0 || p.kc_tiles < 2 || (pp_env != -1 && pp_env != 2)) return false;
   const int64_t tiles = (int64_t)ceil_div_i(p.m, 128) * (p.n / 320);
   return pp_env == 2 || (tiles >= 128 && p.kc_tiles >= 10 && tiles <= 512);
 }
 
-template <int DT, int MODE>
-int launch_gemm(const GemmKParams& p, hipStream_t st) {
+inline GemmPlan plan_gemm(const GemmKParams& p, int mode) {
+  GemmPlan g{};
+  g.splits = 1;
   const int kc = p.c1 + p.c2;
-  const bool dma = kc % BK == 0 && (p.c2 == 0 || p.c1 % BK == 0) && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0);
-  // tuning knobs (experiments): LDS stages of the DMA pipeline, forced tile width
-  static const int nbuf_env = getenv("CA_GEMM_NBUF") ? atoi(getenv("CA_GEMM_NBUF")) : 0;
-  static const int bn_env = getenv("CA_GEMM_BN") ? atoi(getenv("CA_GEMM_BN")) : 0;
+  const bool dma = dma_capable(p);
   const int nt = p.taps * p.kc_tiles;
   if (dma && p.splits > 1) {
     // dense only: 128x320 ping-pong tiles -- the pipelined K loop needs fewer blocks to cover the DMA latency, so fewer
     // (larger) K ranges and slabs: 2048x1280x5120 in 4 ranges x 64 tiles 45 vs 52 us.  (The 8x8-latent convolution
     // 2048x1280x11520 measured 88 vs 82 us this way and stays on the 128x128 schedule.)
-    static const int pp_split_env = getenv("CA_SPLITK_PP") ? atoi(getenv("CA_SPLITK_PP")) : 1;
-    if (pp_split_env && MODE == 0 && p.n % 320 == 0) {
+    static const int pp_split_env = CA_KNOB("CA_SPLITK_PP", 1);
+    if (pp_split_env && mode == 0 && p.n % 320 == 0) {
       const int tiles320 = ceil_div_i(p.m, 128) * (p.n / 320);
       int s_eff = 256 / tiles320;
       if (s_eff > p.splits) s_eff = p.splits;
       if (s_eff >= 2 && tiles320 * s_eff >= 128 && nt / s_eff >= 12) {
-        GemmKParams q = p;
-        q.splits = s_eff;
-        const int rc = ca_launch_gemm_pp(q, DT, MODE, 320, (unsigned)(tiles320 * s_eff), st);
-        hipLaunchKernelGGL((k_splitk_reduce<DT>), dim3(ceil_div_i((int64_t)q.m * (q.n / 8), 256)), dim3(256), 0, st, q);
-        return rc;
+        g.kind = PK_PP2_SPLITK;
+        g.bm = 128, g.bn = 320, g.splits = s_eff, g.tiles = (unsigned)tiles320;
+        return g;
       }
     }
-    const int tiles = ceil_div_i(p.m, 128) * (p.n / 128);
-    hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 1>), dim3(tiles * p.splits), dim3(256), 0, st, p);
-    hipLaunchKernelGGL((k_splitk_reduce<DT>), dim3(ceil_div_i((int64_t)p.m * (p.n / 8), 256)), dim3(256), 0, st, p);
-    return CA_OK;
+    g.kind = PK_DMA_SPLITK;
+    g.bm = 128, g.bn = 128, g.waves_m = 2, g.waves_n = 2, g.nbuf = 1, g.splits = p.splits;
+    g.tiles = (unsigned)(ceil_div_i(p.m, 128) * (p.n / 128));
+    return g;
   }
-  // Ping-pong kernels (ca_gemm_pp*.h; 8 waves, one block per CU, two wave groups alternating between an MFMA segment
-  // and a fragment-read / DMA-issue segment, counted vmcnt).  CA_GEMM_PP: unset = heuristic below, 0 = never,
-  // 2 = 128x320 tiles whenever N % 320 == 0, 4 = the persistent variant with the pipelined epilogue (experiment: see the
-  // warning at the top of ca_gemm_pp3.h),
-  // 1 / 3 = the 256 x 256|128 variant (experimental).  Measured: the 128x320 tile divides every
-  // channel count of the SD1.5 UNet exactly and wins where the 128x128 grid under-fills the chip (<= 2 rounds of
-  // tiles: the 16x16- and 32x32-latent levels, +10..19%); with many rounds the exposed epilogue of a one-block-per-CU
-  // kernel (35..45% of a K = 1280 GEMM) loses against 4 co-resident blocks of k_gemm_dma.
-  static const int pp_env = getenv("CA_GEMM_PP") ? atoi(getenv("CA_GEMM_PP")) : -1;
-  if (MODE == 0 && dma && wres_eligible(p)) return ca_launch_gemm_pp(p, DT, MODE, 160, 0u, st);
+  // Ping-pong kernels (8 waves, one block per CU, two wave groups alternating between an MFMA segment and a
+  // fragment-read / DMA-issue segment, counted vmcnt).  Measured: the 128x320 tile divides every
+  // channel count of the SD1.5 UNet exactly and wins where the 128x128 grid under-fills the chip (<= 2 rounds of tiles:
+  // the 16x16- and 32x32-latent levels, +10..19%); with many rounds the exposed epilogue of a one-block-per-CU kernel
+  // (35..45% of a K = 1280 GEMM) loses against 4 co-resident blocks of k_gemm_dma.
+  static const int pp_env = CA_KNOB("CA_GEMM_PP", -1);  // (experiment builds: 0 = never, 2 = whenever N % 320 == 0, 1 / 3 / 4 = ca_gemm_pp.h / pp3.h)
+  if (mode == 0 && dma && wres_eligible(p)) {
+    g.kind = PK_WRES;
+    g.bm = 256, g.bn = 160;
+    return g;
+  }
   if (dma && pp_env != 0 && pp_env != 3 && nt >= 2 && p.n % 320 == 0 && p.splits <= 1) {  // 128 x 320 tiles
     const int64_t tiles = (int64_t)ceil_div_i(p.m, 128) * (p.n / 320);
+#ifdef CA_EXPERIMENTS
     const int64_t ncols = p.geglu ? p.n / 2 : p.n;
     const bool fits32 = (((int64_t)p.m - 1) * p.ldc + ncols) * 2 < 0x7FFFFF00ll && (!p.res || (((int64_t)p.m - 1) * p.ld_res + p.n) * 2 < 0x7FFFFF00ll) &&
                         p.a_bytes < 0x7FFFFF00u && p.w_bytes < 0x7FFFFF00u && (!p.c2 || p.a2_bytes < 0x7FFFFF00u);
-    const bool pp3_ok = nt >= 5 && !p.out_f32 && fits32 && (!p.rowbias || p.rows_per_group % 64 == 0) && p.ldc % 8 == 0 && (!p.res || p.ld_res % 8 == 0);
-    if (pp3_ok && pp_env == 4) return ca_launch_gemm_pp(p, DT, MODE, 321, (unsigned)tiles, st);
+    const bool pp3_ok = nt >= 5 && !p.out_f32 && !p.ln_parts && fits32 && (!p.rowbias || p.rows_per_group % 64 == 0) && p.ldc % 8 == 0 && (!p.res || p.ld_res % 8 == 0);
+    if (pp3_ok && pp_env == 4) {
+      g.kind = PK_EXP, g.exp = 321, g.tiles = (unsigned)tiles;
+      return g;
+    }
+#endif
     // (thresholds re-checked inside the step, same box, interleaved: dense 768 / 1024 tiles +0.25 ms, conv 512 +0.7, conv 128 +0.2)
-    if (p.row_sums || pp_env == 1 || pp_env == 2 || (pp_env < 0 && tiles >= 128 && nt >= 10 && (tiles <= 256 || (tiles <= 512 && MODE == 0))))
-      return ca_launch_gemm_pp(p, DT, MODE, 320, (unsigned)tiles, st);
+    if (p.row_sums || pp_env == 1 || pp_env == 2 || (pp_env < 0 && tiles >= 128 && nt >= 10 && (tiles <= 256 || (tiles <= 512 && mode == 0)))) {
+      g.kind = PK_PP2;
+      g.bm = 128, g.bn = 320, g.tiles = (unsigned)tiles;
+      return g;
+    }
   }
+#ifdef CA_EXPERIMENTS
   if (dma && (pp_env == 1 || pp_env == 3) && nt >= 2 && p.n % 128 == 0 && p.splits <= 1) {
     const bool bn256 = p.n % 256 == 0;
-    const int64_t tiles = (int64_t)ceil_div_i(p.m, 256) * (p.n / (bn256 ? 256 : 128));
-    return ca_launch_gemm_pp(p, DT, MODE, bn256 ? 256 : 128, (unsigned)tiles, st);
+    g.kind = PK_EXP, g.exp = bn256 ? 256 : 128;
+    g.tiles = (unsigned)((int64_t)ceil_div_i(p.m, 256) * (p.n / (bn256 ? 256 : 128)));
+    return g;
   }
+#endif
   // 128x128 tiles unless N is not a multiple of 128 or the grid would leave CUs idle
   // (8x8 / 16x16 latent levels: M = 2048 / 8192 rows -> < 2 blocks per CU with the big tile).
+  static const int bn_env = CA_KNOB("CA_GEMM_BN", 0);
   bool wide = p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128) >= 512;
   if (bn_env == 64) wide = false;
   if (bn_env == 128 && p.n % 128 == 0) wide = true;
@@ -541,51 +574,96 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   // cover each other's transfer latency: measured +10..25% over double buffering (2 blocks per CU)
   // and far better than 3-4 stage rings (1 block per CU).  Small grids (< 2 blocks per CU) have no
   // co-resident blocks to overlap with and keep the double buffer.
+  static const int nbuf_env = CA_KNOB("CA_GEMM_NBUF", 0);
   int nbuf = nbuf_env ? nbuf_env : (blocks >= 512 ? 1 : 2);
   if (nbuf < 1 || nbuf > 2) nbuf = 2;
   // N = 320 / 960 (every projection and conv of the 64x64-latent level): 128x160 tiles divide N
   // exactly and read the A panel 2 / 6 times instead of 5 / 15 times
-  static const int t160_env = getenv("CA_GEMM_T160") ? atoi(getenv("CA_GEMM_T160")) : 1;
+  static const int t160_env = CA_KNOB("CA_GEMM_T160", 1);
   if (dma && !wide && t160_env && p.n % 160 == 0 && (int64_t)ceil_div_i(p.m, 128) * (p.n / 160) >= 512) {
-    const dim3 grid(ceil_div_i(p.m, 128) * (p.n / 160));
-    hipLaunchKernelGGL((k_gemm_dma<DT, 128, 160, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
-    return CA_OK;
+    g.kind = PK_DMA;
+    g.bm = 128, g.bn = 160, g.waves_m = 2, g.waves_n = 2, g.nbuf = 1;
+    return g;
   }
+#ifdef CA_EXPERIMENTS
   // CA_GEMM_BIG: 1 = 256x128 tiles whenever the grid allows, 3 = the wide feed-forward GEMMs only (the round-1 default:
-  // +4..8% on 8192x10240x1280 and 32768x5120x640 measured in isolation), unset / 0 = never: inside the step, with the
-  // ControlNet stream beside it, the 128x128 tiles are 0.3 ms faster (67.6 vs 67.9, same box, interleaved runs)
-  static const int big_env = getenv("CA_GEMM_BIG") ? atoi(getenv("CA_GEMM_BIG")) : 0;
-  const bool big = big_env == 1 || (big_env == 3 && MODE == 0 && p.n >= 5120 && kc >= 640);
+  // +4..8% on 8192x10240x1280 and 32768x5120x640 measured in isolation; inside the step, with the ControlNet stream
+  // beside it, the 128x128 tiles are 0.3 ms faster), 2 = 4 waves x (128 x 64) per wave, 2 blocks per CU
+  static const int big_env = CA_KNOB("CA_GEMM_BIG", 0);
+  const bool big = big_env == 1 || (big_env == 3 && mode == 0 && p.n >= 5120 && kc >= 640);
   if (dma && big_env == 2 && p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 256) * (p.n / 128) >= 256) {
-    // experiment: 4 waves x (128 x 64) per wave -- 12 instead of 16 fragment reads per 32 MFMAs, 2 blocks per CU
-    const dim3 grid(ceil_div_i(p.m, 256) * (p.n / 128));
-    hipLaunchKernelGGL((k_gemm_dma<DT, 256, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
-    return CA_OK;
+    g.kind = PK_EXP, g.exp = 2562;
+    return g;
   }
   if (dma && big && p.n % 128 == 0 && (int64_t)ceil_div_i(p.m, 256) * (p.n / 128) >= 512) {
-    // 256x128 tiles, 8 waves: 85 instead of 64 flop per byte moved L2 -> LDS, same 4 waves per SIMD
-    const dim3 grid(ceil_div_i(p.m, 256) * (p.n / 128));
-    hipLaunchKernelGGL((k_gemm_dma<DT, 256, 128, 4, 2, MODE, 1>), grid, dim3(512), 0, st, p);
-    return CA_OK;
+    g.kind = PK_EXP, g.exp = 2561;
+    return g;
   }
-  static const int kt_env = getenv("CA_GEMM_KT") ? atoi(getenv("CA_GEMM_KT")) : 64;
+  static const int kt_env = CA_KNOB("CA_GEMM_KT", 64);
   if (wide && dma && kt_env == 32) {
-    const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128));
-    hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 2, 32>), grid, dim3(256), 0, st, p);
-    return CA_OK;
+    g.kind = PK_EXP, g.exp = 32;
+    return g;
   }
-  if (wide) {
-    const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128));
-    if (!dma) hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, st, p);
-    else if (nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 2>), grid, dim3(256), 0, st, p);
-  } else {
-    const dim3 grid(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 64));
-    if (!dma) hipLaunchKernelGGL((k_gemm<DT, 128, 64, 4, 1, MODE>), grid, dim3(256), 0, st, p);
-    else if (nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 2>), grid, dim3(256), 0, st, p);
+#else
+  (void)kc;
+#endif
+  g.kind = dma ? PK_DMA : PK_REG;
+  g.bm = 128, g.bn = wide ? 128 : 64, g.waves_m = wide ? 2 : 4, g.waves_n = wide ? 2 : 1, g.nbuf = dma ? nbuf : 2;
+  return g;
+}
+
+inline void plan_label(const GemmPlan& g, char* buf, int len) {
+  switch (g.kind) {
+    case PK_WRES: snprintf(buf, len, "wres160"); break;
+    case PK_PP2: snprintf(buf, len, "pp128x320"); break;
+    case PK_PP2_SPLITK: snprintf(buf, len, "pp128x320_splitk%d", g.splits); break;
+    case PK_DMA: snprintf(buf, len, "%dx%d%s", g.bm, g.bn, g.nbuf == 2 ? "_db" : ""); break;
+    case PK_DMA_SPLITK: snprintf(buf, len, "128x128_splitk%d", g.splits); break;
+    case PK_REG: snprintf(buf, len, "reg_%dx%d", g.bm, g.bn); break;
+    default: snprintf(buf, len, "exp%d", g.exp); break;
   }
+}
+
+template <int DT, int MODE>
+int launch_gemm(const GemmKParams& p, hipStream_t st) {
+  const GemmPlan g = plan_gemm(p, MODE);
+  const dim3 grid(ceil_div_i(p.m, g.bm ? g.bm : 128) * ceil_div_i(p.n, g.bn ? g.bn : 128));
+  switch (g.kind) {
+    case PK_WRES: return ca_launch_gemm_pp(p, DT, MODE, 160, 0u, st);
+    case PK_PP2: return ca_launch_gemm_pp(p, DT, MODE, 320, g.tiles, st);
+    case PK_PP2_SPLITK: {
+      GemmKParams q = p;
+      q.splits = g.splits;
+      const int rc = ca_launch_gemm_pp(q, DT, MODE, 320, g.tiles * (unsigned)g.splits, st);
+      hipLaunchKernelGGL((k_splitk_reduce<DT>), dim3(ceil_div_i((int64_t)q.m * (q.n / 8), 256)), dim3(256), 0, st, q);
+      return rc;
+    }
+    case PK_DMA_SPLITK:
+      hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 1>), dim3(g.tiles * (unsigned)p.splits), dim3(256), 0, st, p);
+      hipLaunchKernelGGL((k_splitk_reduce<DT>), dim3(ceil_div_i((int64_t)p.m * (p.n / 8), 256)), dim3(256), 0, st, p);
+      return CA_OK;
+    case PK_DMA:
+      if (g.bn == 160) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 160, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
+      else if (g.bn == 128 && g.nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
+      else if (g.bn == 128) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 2>), grid, dim3(256), 0, st, p);
+      else if (g.nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 1>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 2>), grid, dim3(256), 0, st, p);
+      return CA_OK;
+    case PK_REG:
+      if (g.bn == 128) hipLaunchKernelGGL((k_gemm<DT, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_gemm<DT, 128, 64, 4, 1, MODE>), grid, dim3(256), 0, st, p);
+      return CA_OK;
+    default: break;
+  }
+#ifdef CA_EXPERIMENTS
+  if (g.exp == 321 || g.exp == 256 || g.exp == 128) return ca_launch_gemm_pp(p, DT, MODE, g.exp, g.tiles, st);
+  if (g.exp == 2562) hipLaunchKernelGGL((k_gemm_dma<DT, 256, 128, 2, 2, MODE, 1>), dim3(ceil_div_i(p.m, 256) * (p.n / 128)), dim3(256), 0, st, p);
+  if (g.exp == 2561) hipLaunchKernelGGL((k_gemm_dma<DT, 256, 128, 4, 2, MODE, 1>), dim3(ceil_div_i(p.m, 256) * (p.n / 128)), dim3(512), 0, st, p);
+  if (g.exp == 32) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 2, 32>), dim3(ceil_div_i(p.m, 128) * ceil_div_i(p.n, 128)), dim3(256), 0, st, p);
   return CA_OK;
+#else
+  return CA_ERR_LAUNCH;
+#endif
 }
 
 // descriptor size in bytes, or 0 when the buffer is too large for 32-bit offsets (-> register variant)
@@ -666,13 +744,14 @@ static int gemm_fill(const ca_gemm_args* a, GemmKParams& p) {
   return CA_OK;
 }
 
-extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
-  GemmKParams p{};
+// gemm_fill + the split-K decision: everything the plan depends on
+static int gemm_prepare(const ca_gemm_args* a, GemmKParams& p) {
   int rc = gemm_fill(a, p);
   if (rc) return rc;
   {
     const bool dma_ok = (a->k1 + a->k2) % BK == 0 && (a->k2 == 0 || a->k1 % BK == 0);
-    const int s = dma_ok && !p.ln_inline && !p.row_sums ? splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) : 1;
+    // (k_splitk_reduce and the weight-resident kernel read ln_stats as (mean, rstd): partial sums never take those plans)
+    const int s = dma_ok && !p.ln_inline && !p.row_sums && !p.ln_parts ? splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) : 1;
     if (s > 1 && a->workspace && a->workspace_bytes >= (int64_t)s * p.m * p.n * 4) {
       p.splits = s;
       p.partial = reinterpret_cast<float*>(a->workspace);
@@ -681,6 +760,13 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
   CA_REQUIRE(!p.row_sums || (pp2_default_dense(p) && !p.geglu && !p.out_f32), "ca_gemm: row_sums_out is not available for this launch: ask ca_gemm_row_sums_parts() first");
   CA_REQUIRE(!p.ln_inline || wres_eligible(p), "ca_gemm: in-kernel LayerNorm statistics (ln_stats NULL) are not available for this launch: "
              "ask ca_gemm_ln_inline_supported() first and pass ln_stats otherwise");
+  return CA_OK;
+}
+
+extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
+  GemmKParams p{};
+  int rc = gemm_prepare(a, p);
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 0>(p, st);
   else launch_gemm<CA_F16, 0>(p, st);
@@ -691,7 +777,7 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
 extern "C" int64_t ca_gemm_workspace_bytes(const ca_gemm_args* a) {
   if (!a || a->m <= 0 || a->n <= 0 || a->k1 <= 0 || a->k2 < 0) return 0;
   const int kc = a->k1 + a->k2;
-  if (kc % BK != 0 || (a->k2 != 0 && a->k1 % BK != 0) || (a->ln_colsum && !a->ln_stats)) return 0;
+  if (kc % BK != 0 || (a->k2 != 0 && a->k1 % BK != 0) || (a->ln_colsum && !a->ln_stats) || a->ln_parts || a->row_sums_out) return 0;
   const int s = splitk_plan_dense(a->m, a->n, ceil_div_i(kc, BK), a->geglu, a->out_f32);
   return s > 1 ? (int64_t)s * a->m * a->n * 4 : 0;
 }
@@ -704,7 +790,7 @@ extern "C" int ca_gemm_row_sums_parts(const ca_gemm_args* a) {
   if (gemm_fill(&b, p) != CA_OK) return 0;
   const int kc = a->k1 + a->k2;
   const bool dma_ok = kc % BK == 0 && (a->k2 == 0 || a->k1 % BK == 0);
-  if (dma_ok && !p.ln_inline && a->workspace && splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) > 1) return 0;
+  if (dma_ok && !p.ln_inline && !p.ln_parts && a->workspace && splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) > 1) return 0;
   return pp2_default_dense(p) ? p.n / 320 : 0;
 }
 
@@ -725,7 +811,7 @@ extern "C" int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* a) {
   return s > 1 ? (int64_t)s * m * a->cout * 4 : 0;
 }
 
-extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
+static int conv_prepare(const ca_conv_args* a, GemmKParams& p) {
   CA_REQUIRE(a != nullptr, "ca_conv3x3: null args");
   CA_REQUIRE(a->x && a->w && a->y, "ca_conv3x3: null operand");
   CA_REQUIRE(a->images > 0 && a->hin > 0 && a->win > 0, "ca_conv3x3: bad geometry");
@@ -745,7 +831,6 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
   const int wout = (wl + pad - 3) / a->stride + 1;
   const int64_t m64 = (int64_t)a->images * hout * wout;
   CA_REQUIRE(m64 < (1ll << 31), "ca_conv3x3: too many output pixels");
-  GemmKParams p{};
   p.a = (const u16*)a->x;
   p.a2 = (const u16*)a->x2;
   p.w = (const u16*)a->w;
@@ -764,7 +849,7 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
   p.c1 = a->cin1;
   p.c2 = a->cin2;
   p.taps = 9;
-  static const int tap_inner_env = getenv("CA_CONV_TAP_INNER") ? atoi(getenv("CA_CONV_TAP_INNER")) : 1;
+  static const int tap_inner_env = CA_KNOB("CA_CONV_TAP_INNER", 1);
   p.tap_inner = tap_inner_env;  // (0: taps outermost, the round-1 order -- A/B experiments)
   p.kc_tiles = ceil_div_i(a->cin1 + a->cin2, BK);
   p.hin = a->hin;
@@ -790,9 +875,36 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
       p.partial = (float*)a->workspace;
     }
   }
+  return CA_OK;
+}
+
+extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
+  GemmKParams p{};
+  int rc = conv_prepare(a, p);
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 1>(p, st);
   else launch_gemm<CA_F16, 1>(p, st);
   CA_CHECK_LAUNCH("ca_conv3x3");
+  return CA_OK;
+}
+
+// ---- which kernel would these arguments run?  (no launch, no device access: the pointers only have to be non-NULL where
+// the launch requires them)
+extern "C" int ca_gemm_plan_name(const ca_gemm_args* a, char* buf, int32_t len) {
+  CA_REQUIRE(buf && len > 0, "ca_gemm_plan_name: buffer");
+  GemmKParams p{};
+  int rc = gemm_prepare(a, p);
+  if (rc) return rc;
+  plan_label(plan_gemm(p, 0), buf, len);
+  return CA_OK;
+}
+
+extern "C" int ca_conv3x3_plan_name(const ca_conv_args* a, char* buf, int32_t len) {
+  CA_REQUIRE(buf && len > 0, "ca_conv3x3_plan_name: buffer");
+  GemmKParams p{};
+  int rc = conv_prepare(a, p);
+  if (rc) return rc;
+  plan_label(plan_gemm(p, 1), buf, len);
   return CA_OK;
 }

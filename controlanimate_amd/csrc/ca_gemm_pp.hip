@@ -4,10 +4,12 @@
 
 namespace {
 using namespace ca_gemm_detail;
-#include "ca_gemm_pp.h"
 #include "ca_gemm_pp2.h"
-#include "ca_gemm_pp3.h"
 #include "ca_gemm_wres.h"
+#ifdef CA_EXPERIMENTS  // round-2 experiments that never became defaults: not in the product library
+#include "ca_gemm_pp.h"
+#include "ca_gemm_pp3.h"
+#endif
 
 int cu_count() {
   static int n = 0;
@@ -22,6 +24,7 @@ int cu_count() {
 
 template <int DT, int MODE>
 int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
+#ifdef CA_EXPERIMENTS
   if (bn == 321) {  // persistent 128 x 320 kernel with the pipelined epilogue
     const int64_t ncols = p.geglu ? p.n / 2 : p.n;
     const unsigned c_bytes = (unsigned)((((int64_t)p.m - 1) * p.ldc + ncols) * 2);
@@ -56,6 +59,12 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
     hipLaunchKernelGGL((k_gemm_pp3<DT, MODE>), dim3(grid), dim3(512), 0, st, p, (int)tiles, c_bytes, res_bytes);
     return CA_OK;
   }
+  if (bn == 256 || bn == 128) {
+    if (bn == 256) hipLaunchKernelGGL((k_gemm_pp<DT, MODE, 256>), dim3(tiles), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_pp<DT, MODE, 128>), dim3(tiles), dim3(512), 0, st, p);
+    return CA_OK;
+  }
+#endif
   if (bn == 160) {  // weight-resident streaming kernel (K = 320, dense only)
     if (MODE != 0) return CA_ERR_LAUNCH;
     const int panels = p.n / 160;
@@ -69,15 +78,14 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
     hipLaunchKernelGGL((k_gemm_wres<DT>), dim3(8 * per * panels), dim3(512), 0, st, p, panels, 8 * per, chunks, rb_bytes, c_bytes, res_bytes);
     return CA_OK;
   }
-  if (bn == 320) hipLaunchKernelGGL((k_gemm_pp2<DT, MODE>), dim3(tiles), dim3(512), 0, st, p);
-  else if (bn == 256) hipLaunchKernelGGL((k_gemm_pp<DT, MODE, 256>), dim3(tiles), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL((k_gemm_pp<DT, MODE, 128>), dim3(tiles), dim3(512), 0, st, p);
+  if (bn != 320) return CA_ERR_LAUNCH;
+  hipLaunchKernelGGL((k_gemm_pp2<DT, MODE>), dim3(tiles), dim3(512), 0, st, p);
   return CA_OK;
 }
 }  // namespace
 
 int ca_launch_gemm_pp(const ca_gemm_detail::GemmKParams& p0, int dtype, int mode, int bn, unsigned tiles, hipStream_t st) {
-  static const int dbg = getenv("CA_PP_DBG") ? atoi(getenv("CA_PP_DBG")) : 0;
+  static const int dbg = CA_KNOB("CA_PP_DBG", 0);  // (timing experiments: 1 = no epilogue, 2 = no main loop)
   ca_gemm_detail::GemmKParams p = p0;
   p.dbg = dbg;
   if (dtype == CA_BF16) return mode ? launch_pp<CA_BF16, 1>(p, bn, tiles, st) : launch_pp<CA_BF16, 0>(p, bn, tiles, st);

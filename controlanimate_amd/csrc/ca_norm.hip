@@ -503,7 +503,7 @@ __global__ __launch_bounds__(1024) void k_gn_unit(GnParams p, int uc, int units)
 
 // unit width for k_gn_unit: lcm(cpg, 8) if the launch qualifies, else 0
 inline int gn_unit_channels(const GnParams& p) {
-  static const int env = getenv("CA_GN_FUSED") ? atoi(getenv("CA_GN_FUSED")) : 1;
+  static const int env = CA_KNOB("CA_GN_FUSED", 1);
   const int C = p.c1 + p.c2, cpg = C / p.groups;
   if (!env || !p.y || cpg % 8 == 0 || cpg < 8) return 0;  // (cpg >= 8: a 16-byte chunk then touches at most two groups)
   int uc = cpg;
@@ -513,7 +513,7 @@ inline int gn_unit_channels(const GnParams& p) {
 }
 
 inline bool gn_small_ok(const GnParams& p) {
-  static const int env = getenv("CA_GN_FUSED") ? atoi(getenv("CA_GN_FUSED")) : 1;  // 0: always the two-kernel path
+  static const int env = CA_KNOB("CA_GN_FUSED", 1);  // 0: always the two-kernel path
   const int C = p.c1 + p.c2, cpg = C / p.groups;
   return env && p.y && cpg % 8 == 0 && (p.c2 == 0 || p.c1 % cpg == 0) && p.rows_per_stat * (cpg >> 3) <= 256 * GNS_MAX;
 }

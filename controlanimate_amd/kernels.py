@@ -41,6 +41,15 @@ def _req_cuda(*ts):
             raise _capi.CAHipError("HIP kernels need device tensors (no CPU fallback)")
 
 
+_plan_sink = None  # a list: receives the kernel label (ca_gemm_plan_name / ca_conv3x3_plan_name) of every launch -- bench.py, tests
+
+
+def _record_plan(query, args) -> None:
+    if _plan_sink is not None:
+        buf = C.create_string_buffer(64)
+        _plan_sink.append(buf.value.decode() if query(C.byref(args), buf, 64) == 0 else "?")
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
          bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
          rows_per_group: int = 0, residual: Optional[torch.Tensor] = None, alpha: float = 1.0,
@@ -93,6 +102,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         if not isinstance(st, RowStats):
             assert st.dtype == torch.float32 and st.shape == (m, 2) and st.is_contiguous()
             args.ln_stats = _p(st)
+    if hasattr(out, "_row_sums"):  # a caller-supplied `out` reused from an earlier call: its sums describe the old contents
+        del out._row_sums
     if row_sums and _ROW_SUMS_ON and not geglu and not out_f32:
         parts = int(lib().ca_gemm_row_sums_parts(C.byref(args)))
         if parts > 0:  # the epilogue leaves (sum, sum of squares) per row and 320-column tile: the next LayerNorm's statistics
@@ -103,6 +114,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     if wbytes > 0:  # split-K slabs for the 8x8-latent level (allocator-cached, stream-ordered)
         ws = torch.empty((wbytes,), device=a.device, dtype=torch.uint8)
         args.workspace, args.workspace_bytes = _p(ws), wbytes
+    _record_plan(lib().ca_gemm_plan_name, args)
     check(lib().ca_gemm(C.byref(args), _stream()), "ca_gemm")
     return out
 
@@ -177,6 +189,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
     if wbytes > 0:  # split-K slabs for the small-M levels (allocator-cached, stream-ordered)
         ws = torch.empty((wbytes,), device=x.device, dtype=torch.uint8)
         args.workspace, args.workspace_bytes = _p(ws), wbytes
+    _record_plan(lib().ca_conv3x3_plan_name, args)
     check(lib().ca_conv3x3(C.byref(args), _stream()), "ca_conv3x3")
     return y
 

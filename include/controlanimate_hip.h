@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 6
+#define CA_ABI_VERSION 7
 
 /* element types */
 #define CA_BF16 0
@@ -130,6 +130,11 @@ int ca_gemm_row_sums_parts(const ca_gemm_args* args);
 /* 1 if ca_gemm can take these args with ln_stats == NULL (fields other than the pointers' values are what matters;
  * no launch, no device access). */
 int ca_gemm_ln_inline_supported(const ca_gemm_args* args);
+/* ABI v7: the label of the kernel instantiation ca_gemm would launch for these arguments ("wres160", "pp128x320",
+ * "ps128x320", "128x128", "128x160", "128x64_db", "128x128_splitk6", "reg_128x64", ...), written NUL-terminated into
+ * buf[len].  No launch, no device access: the choice is a pure function of the sizes, strides, flags and which pointers
+ * are set (the product library has no tuning environment variables).  Returns CA_OK or the error ca_gemm would return. */
+int ca_gemm_plan_name(const ca_gemm_args* args, char* buf, int32_t len);
 
 /* ------------------------------------------------------------------------------------
  * ca_conv3x3: NHWC 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM
@@ -176,6 +181,8 @@ typedef struct ca_conv_args {
 } ca_conv_args;
 int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* args);
 int ca_conv3x3(const ca_conv_args* args, void* stream);
+/* ABI v7: as ca_gemm_plan_name, for ca_conv3x3 */
+int ca_conv3x3_plan_name(const ca_conv_args* args, char* buf, int32_t len);
 
 /* ------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC, two launches: statistics then apply.

@@ -1,0 +1,136 @@
+"""CPU: which kernel instantiation every GEMM / convolution shape of the benchmark workload (BASELINE config 2:
+16 frames 512x512, CFG batch 2, 1 ControlNet) is dispatched to.
+
+The product library has no tuning environment variables (CA_KNOB compiles to its default), so the choice is a pure
+function of the arguments; `ca_gemm_plan_name` / `ca_conv3x3_plan_name` report it without a launch and this table pins it.
+A threshold edit in `plan_gemm` (csrc/ca_gemm.hip) that silently moves a headline shape to another kernel fails here --
+and the network-level parity test at the headline size (tests/test_fullsize_gpu.py::test_config2_full_size_eps_vs_oracle)
+is what then has to be re-run on the GPU.
+"""
+import ctypes as C
+
+import pytest
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from controlanimate_amd import _build, _capi
+    _build.build(verbose=False)
+    return _capi
+
+
+FAKE = 0x10000  # never dereferenced: the plan only looks at sizes, flags and which pointers are set
+
+
+def gemm_label(capi, m, n, k, *, geglu=0, res=False, ln=None, row_sums=False, workspace=False, k2=0):
+    a = capi.GemmArgs(a=FAKE, w=FAKE, c=FAKE, m=m, n=n, k1=k - k2, k2=k2, lda=k - k2, lda2=k2, ldc=n // 2 if geglu else n,
+                      alpha=1.0, post_scale=1.0, dtype=capi.CA_F16, geglu=geglu, rows_per_group=1)
+    if k2:
+        a.a2 = FAKE
+    if res:
+        a.residual, a.ld_res = FAKE, n
+    if ln == "inline":
+        a.ln_colsum, a.ln_eps = FAKE, 1e-5
+    elif ln == "stats":
+        a.ln_colsum, a.ln_stats, a.ln_eps = FAKE, FAKE, 1e-5
+    elif isinstance(ln, int):
+        a.ln_colsum, a.ln_stats, a.ln_eps, a.ln_parts = FAKE, FAKE, 1e-5, ln
+    if row_sums:
+        a.row_sums_out = FAKE
+    if workspace:
+        a.workspace, a.workspace_bytes = FAKE, 1 << 40
+    buf = C.create_string_buffer(64)
+    rc = capi.lib().ca_gemm_plan_name(C.byref(a), buf, 64)
+    assert rc == 0, capi.lib().ca_last_error()
+    return buf.value.decode()
+
+
+def conv_label(capi, images, h, cin, cout, *, cin2=0, stride=1, upsample=0, workspace=True):
+    a = capi.ConvArgs(x=FAKE, w=FAKE, y=FAKE, images=images, hin=h, win=h, cin1=cin - cin2, cin2=cin2, cout=cout, stride=stride,
+                      upsample=upsample, alpha=1.0, post_scale=1.0, dtype=capi.CA_F16, rows_per_group=1)
+    if cin2:
+        a.x2 = FAKE
+    if workspace:
+        a.workspace, a.workspace_bytes = FAKE, 1 << 40
+    buf = C.create_string_buffer(64)
+    rc = capi.lib().ca_conv3x3_plan_name(C.byref(a), buf, 64)
+    assert rc == 0, capi.lib().ca_last_error()
+    return buf.value.decode()
+
+
+# (M, N, K, keyword flags) -> label.  Rows = the dense launches of one config-2 denoise step (ControlNet + UNet3D,
+# `bench.py --shapes`), largest time share first.
+GEMMS = [
+    ((131072, 2560, 320, dict(geglu=1, ln="inline")), "wres160"),     # FF projection + GEGLU, 64x64 latents
+    ((131072, 320, 320, dict(res=True)), "wres160"),                  # to_out / proj_out (+ residual)
+    ((131072, 320, 320, dict()), "wres160"),                          # proj_in, to_q (cross)
+    ((131072, 960, 320, dict(ln="inline")), "wres160"),               # q|k|v
+    ((32768, 5120, 640, dict(geglu=1, ln=2)), "128x128"),
+    ((32768, 640, 640, dict(res=True, row_sums=True)), "pp128x320"),
+    ((32768, 640, 640, dict()), "pp128x320"),
+    ((32768, 1920, 640, dict(ln=2)), "128x128"),
+    ((8192, 10240, 1280, dict(geglu=1, ln=4)), "128x128"),
+    ((8192, 1280, 1280, dict(res=True, row_sums=True)), "pp128x320"),
+    ((8192, 3840, 1280, dict(ln=4)), "128x128"),
+    ((131072, 320, 1280, dict(res=True)), "128x160"),                 # FF out, 64x64 latents
+    ((32768, 640, 2560, dict(res=True)), "pp128x320"),
+    ((8192, 1280, 5120, dict(res=True)), "pp128x320"),
+    ((2048, 1280, 1280, dict(res=True)), "128x64_db"),
+    ((2048, 1280, 5120, dict(res=True, workspace=True)), "pp128x320_splitk4"),
+    ((2048, 1280, 5120, dict(res=True)), "128x64_db"),                # no scratch handed over: unsplit
+    ((2048, 3840, 1280, dict(ln="stats")), "pp128x320"),
+    ((2048, 10240, 1280, dict(geglu=1, ln="stats")), "pp128x320"),
+    ((131072, 320, 640, dict(k2=320)), "128x160"),                    # shortcut over the skip concat (K = 320 + 320)
+    ((32, 1280, 320, dict()), "128x64_db"),                           # time embedding
+]
+
+# (images, H, Cin, Cout, keyword flags) -> label
+CONVS = [
+    ((32, 64, 320, 320, dict()), "128x160"),
+    ((32, 16, 1280, 1280, dict()), "pp128x320"),
+    ((32, 32, 640, 640, dict()), "128x128"),
+    ((32, 8, 1280, 1280, dict()), "128x128_splitk6"),
+    ((32, 8, 1280, 1280, dict(workspace=False)), "128x64_db"),
+    ((32, 16, 2560, 1280, dict(cin2=1280)), "pp128x320"),
+    ((32, 64, 640, 320, dict(cin2=320)), "128x160"),
+    ((32, 64, 640, 640, dict(upsample=0)), "128x128"),
+    ((32, 32, 1280, 1280, dict()), "128x128"),
+    ((32, 32, 1920, 640, dict(cin2=640)), "128x128"),
+    ((32, 64, 960, 320, dict(cin2=320)), "128x160"),
+    ((32, 64, 320, 320, dict(stride=2)), "pp128x320"),                # Downsample: 32x32 outputs
+    ((32, 16, 1280, 1280, dict(upsample=1)), "128x128"),              # Upsample: 32x32 outputs
+    ((32, 64, 8, 320, dict()), "reg_128x64"),                         # conv_in (4 latent channels padded to 8)
+]
+
+
+@pytest.mark.parametrize("shape,label", GEMMS, ids=[f"gemm{m}x{n}x{k}{'_' + '_'.join(sorted(kw)) if kw else ''}" for (m, n, k, kw), _ in GEMMS])
+def test_gemm_dispatch(capi, shape, label):
+    m, n, k, kw = shape
+    assert gemm_label(capi, m, n, k, **kw) == label
+
+
+@pytest.mark.parametrize("shape,label", CONVS, ids=[f"conv{i}x{h}x{h}_{ci}to{co}{'_' + '_'.join(sorted(kw)) if kw else ''}" for (i, h, ci, co, kw), _ in CONVS])
+def test_conv_dispatch(capi, shape, label):
+    i, h, ci, co, kw = shape
+    assert conv_label(capi, i, h, ci, co, **kw) == label
+
+
+def test_partial_layernorm_sums_never_reach_a_kernel_that_reads_mean_rstd(capi):
+    """ln_parts = P hands [M][P][2] partial sums over; only the tiled epilogue finishes them.  The split-K
+    reduce kernel and the weight-resident kernel read ln_stats as (mean, rstd): such a launch must take neither."""
+    lib = capi.lib()
+    # the shape that would split (2048 x 1280 x 5120 with scratch) stays unsplit with ln_parts
+    assert gemm_label(capi, 2048, 1280, 5120, ln=4, workspace=True) == "128x64_db"
+    assert gemm_label(capi, 2048, 1280, 5120, ln="stats", workspace=True) == "pp128x320_splitk4"
+    # the weight-resident shape (K = 320, M >= 16384) stays on the tiled kernels with ln_parts
+    assert gemm_label(capi, 131072, 960, 320, ln=1) == "128x160"
+    a = capi.GemmArgs(a=FAKE, w=FAKE, c=FAKE, m=2048, n=1280, k1=5120, lda=5120, ldc=1280, alpha=1.0, post_scale=1.0, dtype=capi.CA_F16,
+                      ln_colsum=FAKE, ln_stats=FAKE, ln_eps=1e-5, ln_parts=4)
+    assert lib.ca_gemm_workspace_bytes(C.byref(a)) == 0
+    a.ln_parts = 0
+    assert lib.ca_gemm_workspace_bytes(C.byref(a)) > 0
+    # malformed: partial sums without the statistics pointer
+    bad = capi.GemmArgs(a=FAKE, w=FAKE, c=FAKE, m=2048, n=1280, k1=1280, lda=1280, ldc=1280, alpha=1.0, post_scale=1.0, dtype=capi.CA_F16,
+                        ln_colsum=FAKE, ln_eps=1e-5, ln_parts=4)
+    buf = C.create_string_buffer(64)
+    assert lib.ca_gemm_plan_name(C.byref(bad), buf, 64) < 0 and b"ln_parts" in lib.ca_last_error()
