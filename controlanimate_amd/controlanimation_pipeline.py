@@ -42,10 +42,15 @@ class AnimationPipelineOutput:
 class ControlAnimationPipeline:
     def __init__(self, vae, text_encoder, tokenizer, unet, scheduler=None):
         self.overlap_controlnet = True  # ControlNet stack on a second HIP stream beside the UNet encoder
-        # True: step 0 of a window runs eagerly (it also warms the prompt / hint caches), then the ControlNet +
-        # UNet part of a step is captured once as a hipGraph and replayed for the remaining steps (static
-        # input buffer, device-side timestep) -- same kernels, bit-identical results, ~1 ms of host time per step
-        self.use_hip_graph = False
+        # True (the default): the ControlNet + UNet part of a step is captured ONCE as a hipGraph -- in the first window, after
+        # an eager step 0 that warms the prompt / hint caches and the allocator pools -- and replayed for every later step of
+        # EVERY later window with the same signature (shapes, models, sampler family): static input buffers, device-side
+        # timestep, the window's prompt embeddings / control frames copied into the tensors the captured kernels read and
+        # the per-window caches refreshed in place.  Same kernels, bit-identical results (tests/test_graph_gpu.py), ~1 ms
+        # instead of ~50 ms of host time per step: with 8 ranks on one host the loop stays GPU-bound.  A failed capture is
+        # logged and the window runs eagerly (`graph_fallback_reason`).
+        self.use_hip_graph = True
+        self._graph_state = None
         if scheduler is None:  # native LCM (reference :95-101)
             scheduler = LCMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", prediction_type="epsilon")
         self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
@@ -308,11 +313,36 @@ class ControlAnimationPipeline:
         use_graph = bool(self.use_hip_graph) and device.type == "cuda" and len(timesteps) > 1
         self.graph_replays = 0
         self.graph_fallback_reason = None
-        x_static = t_static = graph = eps_static = None
+        gs = None
         if use_graph:
             hh, ww = latents.shape[3], latents.shape[4]
-            x_static = torch.empty((rep * f, hh, ww, cpad), device=device, dtype=unet.act_dtype)
-            t_static = torch.zeros(1, device=device, dtype=torch.float32)
+            nets = list(getattr(cn, "controlnets", [])) if cn is not None else []
+            sig = (id(unet), id(unet.arena), tuple(id(n.arena) for n in nets), id(cn), rep, f, hh, ww, cpad, str(unet.act_dtype),
+                   tuple(unet_prompt.shape), tuple(cn_prompt.shape) if cn is not None else None, bool(cn_single), bool(guess_mode),
+                   bool(use_lcm), w_embedding is not None, bool(getattr(self, "overlap_controlnet", True)),
+                   tuple(tuple(pi.shape) for pi in cn.prep_images) if cn is not None else None,
+                   tuple(id(pi) for pi in cn.prep_images) if cn is not None else None,
+                   # host-side scalars that are baked into captured launches
+                   tuple(float(c) for c in cn.cond_scale) if cn is not None else None,
+                   float(ipa_scale) if self.ip_adapter is not None else None)
+            gs = self._graph_state
+            if gs is None or gs["sig"] != sig:
+                gs = self._graph_state = {
+                    "sig": sig, "graph": None, "eps": None,
+                    "x": torch.empty((rep * f, hh, ww, cpad), device=device, dtype=unet.act_dtype),
+                    "t": torch.zeros(1, device=device, dtype=torch.float32),
+                    "unet_prompt": torch.empty_like(unet_prompt), "cn_prompt": torch.empty_like(cn_prompt),
+                    "w": None if w_embedding is None else torch.empty_like(w_embedding)}
+            # this window's conditioning goes INTO the tensors the (possibly already captured) kernels read
+            gs["unet_prompt"].copy_(unet_prompt)
+            gs["cn_prompt"].copy_(cn_prompt)
+            if w_embedding is not None:
+                gs["w"].copy_(w_embedding)
+            unet_prompt, cn_prompt, w_embedding = gs["unet_prompt"], gs["cn_prompt"], gs["w"]
+            if gs["graph"] is not None:  # a later window: the per-window caches (text / IP K/V, hint embeddings), in place
+                unet.refresh_window_caches()
+                for n_ in nets:
+                    n_.refresh_window_caches()
 
         def model_eps(x, tt):
             down = mid = None
@@ -326,42 +356,58 @@ class ControlAnimationPipeline:
             # x = latents_to_nhwc(latents, rep): for rep == 2 the two CFG halves are the same tensor (reference :797)
             return unet.forward_nhwc(x, rep, f, tt, unet_prompt, down, mid, timestep_cond=w_embedding, cfg_identical_halves=rep == 2)
 
+        # The sampler's noise: the reference draws one CPU tensor per step inside the loop (:1601 `torch.randn`, global RNG;
+        # diffusers' randn_tensor with the CPU generator) and uploads it.  The SAME values are drawn here in one go (one
+        # `randn` of n x shape reproduces n consecutive draws when numel % 16 == 0 -- checked by tests/test_host_logic.py --
+        # else n draws in a row) and uploaded once, while step 0's kernels run: no per-step host work on the critical path.
+        needs_noise = bool(sched.needs_noise and len(sched.timesteps) > 1)
+        native_noise = isinstance(sched, LCMScheduler) and not isinstance(sched, DiffusersLCMScheduler)
+        noise_all = None
+
+        def draw_all_noise():
+            n_steps, shape = len(timesteps), tuple(latents.shape)
+            gen = None if native_noise else generator
+            if latents.numel() % 16 == 0:
+                big = torch.randn((n_steps,) + shape, generator=gen, dtype=torch.float32)
+            else:
+                big = torch.stack([torch.randn(shape, generator=gen, dtype=torch.float32) for _ in range(n_steps)])
+            return big.to(device)
+
         for i, t in enumerate(timesteps):
             idx = first + i
             in_scale = sched.input_scale(idx)
             if use_graph:
-                K.latents_to_nhwc(latents, cpad, rep, in_scale, unet.act_dtype, out=x_static)   # [(rep f), h, w, 8]
-                t_static.fill_(float(t))
-                if graph is None and i >= 1:  # caches and allocator pools are warm after the eager step 0
+                K.latents_to_nhwc(latents, cpad, rep, in_scale, unet.act_dtype, out=gs["x"])   # [(rep f), h, w, 8]
+                gs["t"].fill_(float(t))
+                if gs["graph"] is None and i >= 1:  # caches and allocator pools are warm after the eager step 0
                     try:
                         torch.cuda.synchronize()
                         g_ = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g_):
-                            eps_static = model_eps(x_static, t_static)
-                        graph = g_
+                            gs["eps"] = model_eps(gs["x"], gs["t"])
+                        gs["graph"] = g_
                     except Exception as exc:  # capture is an optimisation only -- but never a silent one
-                        use_graph, graph = False, None
+                        use_graph = False
+                        self._graph_state = None
                         self.graph_fallback_reason = f"{type(exc).__name__}: {exc}"
                         logger.warning("hipGraph capture failed (%s); this window runs eagerly", self.graph_fallback_reason)
                         torch.cuda.synchronize()
-                if graph is not None:
-                    graph.replay()
+                if use_graph and gs["graph"] is not None:
+                    gs["graph"].replay()
                     self.graph_replays += 1
-                    eps = eps_static
+                    eps = gs["eps"]
                 else:
-                    eps = model_eps(x_static, t_static)
+                    eps = model_eps(gs["x"], gs["t"])
             else:
                 x = K.latents_to_nhwc(latents, cpad, rep, in_scale, unet.act_dtype)          # [(rep f), h, w, 8]
                 eps = model_eps(x, t)
             if self.record_eps:
                 self.eps_history.append(K.nhwc_to_ncfhw_f32(eps, rep, 4, f).cpu())
             noise = None
-            if sched.needs_noise and len(sched.timesteps) > 1:
-                if isinstance(sched, LCMScheduler) and not isinstance(sched, DiffusersLCMScheduler):
-                    noise = torch.randn(latents.shape)  # global CPU RNG, as the reference (:1601)
-                else:
-                    noise = torch.randn(latents.shape, generator=generator, dtype=torch.float32)  # randn_tensor with the CPU generator
-                noise = noise.to(device)
+            if needs_noise:
+                if noise_all is None:
+                    noise_all = draw_all_noise()
+                noise = noise_all[i]
             if getattr(sched, "multistep", False):
                 # history-carrying samplers (DPM-Solver++, LMS, PNDM): CFG combine, then one linear-combination launch
                 e = K.cfg_combined_eps(eps, rep, guidance_scale if rep == 2 else 1.0, latents)

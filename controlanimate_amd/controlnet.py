@@ -100,6 +100,7 @@ class ControlNetModel(HipModelMixin, nn.Module):
             nn.init.zeros_(m.weight)  # zero convs; checkpoints overwrite them
         self._hint_key = None
         self._hint_emb = None
+        self._hint_doubled = False
 
     @classmethod
     def from_config(cls, config: dict, **kwargs):
@@ -112,7 +113,10 @@ class ControlNetModel(HipModelMixin, nn.Module):
         """controlnet_cond [B,3,H,W] in [0,1] -> NHWC embedding [B,H/8,W/8,C0]; cached while the same
         (unmodified) tensor object is passed, i.e. for all denoising steps of a window."""
         key = self._hint_key
-        if key is not None and key[0] is controlnet_cond and key[1] == controlnet_cond._version and self._hint_emb is not None:
+        if key is not None and key[0] is controlnet_cond and self._hint_emb is not None:
+            if key[1] != controlnet_cond._version:  # the same tensor with new contents (the next window's frames): in place
+                self._hint_emb.copy_(self._embed_hints(controlnet_cond, device))
+                self._hint_key = (controlnet_cond, controlnet_cond._version)
             return self._hint_emb
         self._hint_emb = self._embed_hints(controlnet_cond, device)
         self._hint_key = (controlnet_cond, controlnet_cond._version)
@@ -127,6 +131,11 @@ class ControlNetModel(HipModelMixin, nn.Module):
         cond = controlnet_cond
         doubled = bool(getattr(cond, "_cfg_doubled", False)) and cond.shape[0] % 2 == 0
         if doubled:
+            half = cond.shape[0] // 2
+            # the mark is a hint, the tensor is the truth: a caller may have edited one half in place since (regional control)
+            doubled = bool(torch.equal(cond[:half], cond[half:]))
+        self._hint_doubled = doubled  # what forward_nhwc may rely on for THIS embedding (the shared prefix of the CFG halves)
+        if doubled:
             cond = cond[: cond.shape[0] // 2]
         emb = ce(K.ncfhw_to_nhwc(cond.to(device).unsqueeze(2), ce.conv_in.cin_pad, self.act_dtype))
         return torch.cat([emb, emb]) if doubled else emb
@@ -135,7 +144,9 @@ class ControlNetModel(HipModelMixin, nn.Module):
         """HipModelMixin.refresh_window_caches + the hint embedding of the current control images (in place)."""
         n = super().refresh_window_caches()
         if self._hint_key is not None and self._hint_emb is not None:
-            self._hint_emb.copy_(self._embed_hints(self._hint_key[0], self._hint_emb.device))
+            src = self._hint_key[0]
+            self._hint_emb.copy_(self._embed_hints(src, self._hint_emb.device))
+            self._hint_key = (src, src._version)
             n += 1
         return n
 
@@ -170,7 +181,7 @@ class ControlNetModel(HipModelMixin, nn.Module):
         # halves are identical up to the first cross-attention -- see UNet3DConditionModel.forward_nhwc
         first = self.down_blocks[0]
         from .unet import _CFG_SHARED_ON
-        shared = (cfg_identical_halves and _CFG_SHARED_ON and images % 2 == 0 and bool(getattr(controlnet_cond, "_cfg_doubled", False)) and
+        shared = (cfg_identical_halves and _CFG_SHARED_ON and images % 2 == 0 and bool(getattr(self, "_hint_doubled", False)) and
                   getattr(first, "has_cross_attention", False) and (not torch.is_tensor(timestep) or timestep.numel() == 1))
         if shared:
             half = images // 2

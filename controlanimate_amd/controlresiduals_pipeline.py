@@ -83,9 +83,16 @@ class MultiControlNetResidualsPipeline:
             src = images[name] if isinstance(images, dict) else images
             frames = [_image_to_chw01(self.prepare_controlnet_input_image(name, im)) for im in src]
             ctrl = torch.stack(frames).to(self.device)
-            if do_classifier_free_guidance and not guess_mode and not self.use_lcm:
+            doubled = bool(do_classifier_free_guidance and not guess_mode and not self.use_lcm)
+            if doubled:
                 ctrl = torch.cat([ctrl] * 2)
-                ctrl._cfg_doubled = True  # (both halves are the same frames: the hint embedding is computed for one)
+            old = self.prep_images[len(prep)] if self.prep_images is not None and len(self.prep_images) == len(self.controlnet_names) else None
+            if old is not None and old.shape == ctrl.shape and old.dtype == ctrl.dtype and old.device == ctrl.device:
+                # the next window's frames go INTO the tensor the ControlNets already know: their hint embeddings are then
+                # refreshed in place (ControlNetModel.hint_embedding) and a captured hipGraph of the step stays valid
+                old.copy_(ctrl)
+                ctrl = old
+            ctrl._cfg_doubled = doubled  # (both halves are the same frames: the hint embedding is computed for one; verified there)
             prep.append(ctrl)
         self.prep_images = prep
 

@@ -475,6 +475,7 @@ enum PlanKind {
   PK_DMA,         // k_gemm_dma<bm, bn>: LDS-DMA staging, nbuf LDS stages
   PK_DMA_SPLITK,  // k_gemm_dma<128,128> K ranges + k_splitk_reduce
   PK_REG,         // k_gemm<bm, bn>: register-staged (channel counts the DMA path cannot take)
+  PK_PS,          // persistent streaming kernel, 128 x 320 tiles (ca_gemm_ps.h)
   PK_EXP,         // experiment builds only: `exp` selects (see launch_gemm)
 };
 struct GemmPlan {
@@ -490,13 +491,15 @@ inline bool dma_capable(const GemmKParams& p) {
   return kc % BK == 0 && (p.c2 == 0 || p.c1 % BK == 0) && p.a_bytes != 0 && p.w_bytes != 0 && (p.c2 == 0 || p.a2_bytes != 0);
 }
 
-// Dense launches the plan sends to the 128 x 320 ping-pong kernel whatever else is asked (whose epilogue can leave
-// per-row sums of its output: ca_gemm_args.row_sums_out).
-inline bool pp2_default_dense(const GemmKParams& p) {
-  static const int pp_env = CA_KNOB("CA_GEMM_PP", -1);
-  if (!dma_capable(p) || p.taps != 1 || p.splits > 1 || wres_eligible(p) || p.n % 320 != 0 || p.kc_tiles < 2 || (pp_env != -1 && pp_env != 2)) return false;
-  const int64_t tiles = (int64_t)ceil_div_i(p.m, 128) * (p.n / 320);
-  return pp_env == 2 || (tiles >= 128 && p.kc_tiles >= 10 && tiles <= 512);
+// Persistent streaming kernel (ca_gemm_ps.h): can this launch run on it?
+inline bool ps_capable(const GemmKParams& p) {
+  const int nt = p.taps * p.kc_tiles;
+  const int64_t ncols = p.geglu ? p.n / 2 : p.n;
+  const bool fits32 = (((int64_t)p.m - 1) * p.ldc + ncols) * 2 < 0x7FFFFF00ll && (!p.res || (((int64_t)p.m - 1) * p.ld_res + p.n) * 2 < 0x7FFFFF00ll) &&
+                      p.a_bytes < 0x7FFFFF00u && p.w_bytes < 0x7FFFFF00u && (!p.c2 || p.a2_bytes < 0x7FFFFF00u);
+  const bool aligned = ((uintptr_t)p.c & 15) == 0 && (!p.res || ((uintptr_t)p.res & 15) == 0) && p.ldc % 8 == 0 && (!p.res || p.ld_res % 8 == 0);
+  return dma_capable(p) && p.n % 320 == 0 && nt >= 2 && p.splits <= 1 && !p.out_f32 && !p.ln_inline && (p.ln_parts <= 2 || p.ln_parts == 4) && fits32 && aligned &&
+         (!p.rowbias || p.rows_per_group % 64 == 0) && !(p.geglu && (p.res || p.row_sums)) && p.post == 1.f && p.act == CA_ACT_NONE;
 }
 
 inline GemmPlan plan_gemm(const GemmKParams& p, int mode) {
@@ -531,6 +534,24 @@ inline GemmPlan plan_gemm(const GemmKParams& p, int mode) {
   // the 16x16- and 32x32-latent levels, +10..19%); with many rounds the exposed epilogue of a one-block-per-CU kernel
   // (35..45% of a K = 1280 GEMM) loses against 4 co-resident blocks of k_gemm_dma.
   static const int pp_env = CA_KNOB("CA_GEMM_PP", -1);  // (experiment builds: 0 = never, 2 = whenever N % 320 == 0, 1 / 3 / 4 = ca_gemm_pp.h / pp3.h)
+  // Persistent streaming kernel (ca_gemm_ps.h): same main loop as the 128 x 320 ping-pong kernel, but no launch / prologue
+  // bubble per tile and an epilogue whose stores nothing waits for.  Measured against the kernel each shape had before
+  // (tools/ps_check.py --time, same box): 131072x320x1280 149 vs 180 us, 32768x640x640 50 vs 58, 8192x1280x1280 41.6 vs 43.3,
+  // 8192x10240x1280 GEGLU 261 vs 270, 2048x10240x1280 GEGLU 67.6 vs 71.0, 32768x5120x640 GEGLU 321 vs 327; behind on long K
+  // loops (its flag pieces cost ~5% of the main loop: 32768x640x2560 134 vs 122, 8192x1280x5120 114 vs 109), on wide plain
+  // outputs where four co-resident 128x128 blocks already hide their epilogues (32768x1920x640 116 vs 107) and on every
+  // convolution (-10..-25%).  Hence: dense, 2..20 K tiles, at least one tile per CU, GEGLU or at most four column tiles.
+  // CA_GEMM_PS (experiment builds): 0 = never, 1 = every launch it can take, 2 = the same except the weight-resident kernel's.
+  static const int ps_env = CA_KNOB("CA_GEMM_PS", -1);
+  if (ps_env != 0 && ps_capable(p)) {
+    const int64_t tiles = (int64_t)ceil_div_i(p.m, 128) * (p.n / 320);
+    const bool dflt = mode == 0 && !wres_eligible(p) && nt <= 20 && tiles >= 256 && (p.geglu || p.n <= 1280);
+    if ((ps_env < 0 && dflt) || ps_env == 1 || (ps_env == 2 && !(mode == 0 && wres_eligible(p)))) {
+      g.kind = PK_PS;
+      g.bm = 128, g.bn = 320, g.tiles = (unsigned)tiles;
+      return g;
+    }
+  }
   if (mode == 0 && dma && wres_eligible(p)) {
     g.kind = PK_WRES;
     g.bm = 256, g.bn = 160;
@@ -612,10 +633,19 @@ inline GemmPlan plan_gemm(const GemmKParams& p, int mode) {
   return g;
 }
 
+// can the epilogue of this (dense) launch leave per-row sums of its output (ca_gemm_args.row_sums_out)?  Only the 128 x 320
+// tile kernels do; the answer is about the launch the arguments get WITHOUT the pointer.
+inline bool row_sums_capable(GemmKParams p) {
+  p.row_sums = nullptr;
+  const int k = plan_gemm(p, 0).kind;
+  return (k == PK_PP2 || k == PK_PS) && !p.geglu && !p.out_f32;
+}
+
 inline void plan_label(const GemmPlan& g, char* buf, int len) {
   switch (g.kind) {
     case PK_WRES: snprintf(buf, len, "wres160"); break;
     case PK_PP2: snprintf(buf, len, "pp128x320"); break;
+    case PK_PS: snprintf(buf, len, "ps128x320"); break;
     case PK_PP2_SPLITK: snprintf(buf, len, "pp128x320_splitk%d", g.splits); break;
     case PK_DMA: snprintf(buf, len, "%dx%d%s", g.bm, g.bn, g.nbuf == 2 ? "_db" : ""); break;
     case PK_DMA_SPLITK: snprintf(buf, len, "128x128_splitk%d", g.splits); break;
@@ -631,6 +661,7 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   switch (g.kind) {
     case PK_WRES: return ca_launch_gemm_pp(p, DT, MODE, 160, 0u, st);
     case PK_PP2: return ca_launch_gemm_pp(p, DT, MODE, 320, g.tiles, st);
+    case PK_PS: return ca_launch_gemm_pp(p, DT, MODE, 322, g.tiles, st);
     case PK_PP2_SPLITK: {
       GemmKParams q = p;
       q.splits = g.splits;
@@ -757,7 +788,7 @@ static int gemm_prepare(const ca_gemm_args* a, GemmKParams& p) {
       p.partial = reinterpret_cast<float*>(a->workspace);
     }
   }
-  CA_REQUIRE(!p.row_sums || (pp2_default_dense(p) && !p.geglu && !p.out_f32), "ca_gemm: row_sums_out is not available for this launch: ask ca_gemm_row_sums_parts() first");
+  CA_REQUIRE(!p.row_sums || row_sums_capable(p), "ca_gemm: row_sums_out is not available for this launch: ask ca_gemm_row_sums_parts() first");
   CA_REQUIRE(!p.ln_inline || wres_eligible(p), "ca_gemm: in-kernel LayerNorm statistics (ln_stats NULL) are not available for this launch: "
              "ask ca_gemm_ln_inline_supported() first and pass ln_stats otherwise");
   return CA_OK;
@@ -791,7 +822,7 @@ extern "C" int ca_gemm_row_sums_parts(const ca_gemm_args* a) {
   const int kc = a->k1 + a->k2;
   const bool dma_ok = kc % BK == 0 && (a->k2 == 0 || a->k1 % BK == 0);
   if (dma_ok && !p.ln_inline && !p.ln_parts && a->workspace && splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) > 1) return 0;
-  return pp2_default_dense(p) ? p.n / 320 : 0;
+  return row_sums_capable(p) ? p.n / 320 : 0;
 }
 
 extern "C" int ca_gemm_ln_inline_supported(const ca_gemm_args* a) {

@@ -114,13 +114,18 @@ class HipModelMixin:
 
     def refresh_window_caches(self) -> int:
         """Recomputes, IN PLACE, everything this model caches across the denoising steps of a window from the prompt:
-        the text K/V of every cross-attention site (and the IP-Adapter K/V).  The pipeline gets this for free (the first
-        step of a window runs eagerly and fills the caches); a benchmark that replays a captured hipGraph calls it once
-        per window so that the per-window work stays inside the timed region.  Returns the number of GEMMs issued."""
-        cache = self._cache
+        the activation-dtype copy of the prompt embeddings, the text K/V of every cross-attention site (and the IP-Adapter
+        K/V).  In place = every cached buffer keeps its address, so a captured hipGraph that reads them stays valid: the
+        pipeline keeps ONE prompt tensor per signature, copies each window's embeddings into it and calls this before it
+        replays (ControlAnimationPipeline.__call__); a forward that is handed the same tensor object with new contents
+        does the same on its own (`_prompt`).  Returns the number of GEMMs issued."""
+        cache, key = self._cache, self._cache_key
         ehs = cache.get("ehs")
-        if ehs is None:
+        if ehs is None or key is None:
             return 0
+        src = key[0]
+        ehs.copy_(src.to(device=ehs.device, dtype=ehs.dtype))
+        self._cache_key = (src, src._version)
         nb, L, cd = ehs.shape
         n = 0
         for m in self.modules():
@@ -234,7 +239,10 @@ class HipModelMixin:
         """Prompt embeddings in the activation dtype + the K/V cache that belongs to them. The cache
         survives across calls only while the caller passes the very same (unmodified) tensor."""
         key = self._cache_key
-        if key is not None and key[0] is encoder_hidden_states and key[1] == encoder_hidden_states._version:
+        if key is not None and key[0] is encoder_hidden_states and "ehs" in self._cache and \
+                tuple(self._cache["ehs"].shape) == tuple(encoder_hidden_states.shape):
+            if key[1] != encoder_hidden_states._version:  # the same tensor with new contents: refresh in place (addresses stay)
+                self.refresh_window_caches()
             return self._cache["ehs"], self._cache
         ehs = encoder_hidden_states.to(device=device, dtype=self.act_dtype).contiguous()
         self._cache = {"ehs": ehs}

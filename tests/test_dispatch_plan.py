@@ -59,28 +59,30 @@ def conv_label(capi, images, h, cin, cout, *, cin2=0, stride=1, upsample=0, work
 
 
 # (M, N, K, keyword flags) -> label.  Rows = the dense launches of one config-2 denoise step (ControlNet + UNet3D,
-# `bench.py --shapes`), largest time share first.
+# `bench.py --shapes`), largest time share first.  Labels: wres160 = weight-resident K = 320 kernel, ps128x320 = persistent
+# streaming kernel (round 3), pp128x320 = ping-pong 128 x 320 tiles, BMxBN = k_gemm_dma tiles (_db: two LDS stages),
+# _splitkS = S K ranges + reduce, reg_ = register-staged fallback.
 GEMMS = [
     ((131072, 2560, 320, dict(geglu=1, ln="inline")), "wres160"),     # FF projection + GEGLU, 64x64 latents
     ((131072, 320, 320, dict(res=True)), "wres160"),                  # to_out / proj_out (+ residual)
     ((131072, 320, 320, dict()), "wres160"),                          # proj_in, to_q (cross)
     ((131072, 960, 320, dict(ln="inline")), "wres160"),               # q|k|v
-    ((32768, 5120, 640, dict(geglu=1, ln=2)), "128x128"),
-    ((32768, 640, 640, dict(res=True, row_sums=True)), "pp128x320"),
-    ((32768, 640, 640, dict()), "pp128x320"),
+    ((32768, 5120, 640, dict(geglu=1, ln=2)), "ps128x320"),
+    ((32768, 640, 640, dict(res=True, row_sums=True)), "ps128x320"),
+    ((32768, 640, 640, dict()), "ps128x320"),
     ((32768, 1920, 640, dict(ln=2)), "128x128"),
-    ((8192, 10240, 1280, dict(geglu=1, ln=4)), "128x128"),
-    ((8192, 1280, 1280, dict(res=True, row_sums=True)), "pp128x320"),
+    ((8192, 10240, 1280, dict(geglu=1, ln=4)), "ps128x320"),
+    ((8192, 1280, 1280, dict(res=True, row_sums=True)), "ps128x320"),
     ((8192, 3840, 1280, dict(ln=4)), "128x128"),
-    ((131072, 320, 1280, dict(res=True)), "128x160"),                 # FF out, 64x64 latents
+    ((131072, 320, 1280, dict(res=True)), "ps128x320"),               # FF out, 64x64 latents
     ((32768, 640, 2560, dict(res=True)), "pp128x320"),
     ((8192, 1280, 5120, dict(res=True)), "pp128x320"),
     ((2048, 1280, 1280, dict(res=True)), "128x64_db"),
     ((2048, 1280, 5120, dict(res=True, workspace=True)), "pp128x320_splitk4"),
     ((2048, 1280, 5120, dict(res=True)), "128x64_db"),                # no scratch handed over: unsplit
     ((2048, 3840, 1280, dict(ln="stats")), "pp128x320"),
-    ((2048, 10240, 1280, dict(geglu=1, ln="stats")), "pp128x320"),
-    ((131072, 320, 640, dict(k2=320)), "128x160"),                    # shortcut over the skip concat (K = 320 + 320)
+    ((2048, 10240, 1280, dict(geglu=1, ln="stats")), "ps128x320"),
+    ((131072, 320, 640, dict(k2=320)), "ps128x320"),                  # shortcut over the skip concat (K = 320 + 320)
     ((32, 1280, 320, dict()), "128x64_db"),                           # time embedding
 ]
 
@@ -122,8 +124,9 @@ def test_partial_layernorm_sums_never_reach_a_kernel_that_reads_mean_rstd(capi):
     # the shape that would split (2048 x 1280 x 5120 with scratch) stays unsplit with ln_parts
     assert gemm_label(capi, 2048, 1280, 5120, ln=4, workspace=True) == "128x64_db"
     assert gemm_label(capi, 2048, 1280, 5120, ln="stats", workspace=True) == "pp128x320_splitk4"
-    # the weight-resident shape (K = 320, M >= 16384) stays on the tiled kernels with ln_parts
-    assert gemm_label(capi, 131072, 960, 320, ln=1) == "128x160"
+    # the weight-resident shape (K = 320, M >= 16384) goes to a kernel whose epilogue finishes partial sums
+    assert gemm_label(capi, 131072, 960, 320, ln=1) == "ps128x320"
+    assert gemm_label(capi, 131072, 960, 320, ln="stats") == "wres160"
     a = capi.GemmArgs(a=FAKE, w=FAKE, c=FAKE, m=2048, n=1280, k1=5120, lda=5120, ldc=1280, alpha=1.0, post_scale=1.0, dtype=capi.CA_F16,
                       ln_colsum=FAKE, ln_stats=FAKE, ln_eps=1e-5, ln_parts=4)
     assert lib.ca_gemm_workspace_bytes(C.byref(a)) == 0

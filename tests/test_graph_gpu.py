@@ -85,3 +85,52 @@ def test_pipeline_hip_graph_option_is_bit_identical(scenario):
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.isfinite(outs[0][0]).all()
+
+
+@pytest.mark.parametrize("scenario", ["lcm_cfg_controlnet", "native_lcm_guess"])
+def test_pipeline_graph_persists_across_windows(scenario):
+    """The product default (use_hip_graph=True): ONE capture serves every later window of the same signature -- each
+    window brings new prompt embeddings and new control frames, which are copied into the tensors the captured kernels
+    read, the per-window caches (text K/V, hint embedding) are refreshed in place, and every step of windows 2, 3 replays.
+    Three windows with the graph == the same three windows eagerly, bit for bit (latents of every step)."""
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+    from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.schedulers import get_scheduler
+    from tests.test_pipeline_gpu import build
+    native = scenario == "native_lcm_guess"
+    ucfg, uw, unet, ccfg, cws, nets = build("v2", seed=61, n_controlnets=1, **({"time_cond_proj_dim": 256} if native else {}))
+    f, hw, nsteps = 8, 8, 4
+    g = torch.Generator().manual_seed(19)
+    windows = [dict(pos=torch.randn(1, 77, 768, generator=g) * 0.5, neg=torch.randn(1, 77, 768, generator=g) * 0.5,
+                    hints=torch.rand(f, 3, 8 * hw, 8 * hw, generator=g), lat=torch.randn(1, 4, f, hw, hw, generator=g) * 0.8) for _ in range(3)]
+    runs = []
+    for use_graph in (False, True):
+        sched = None if native else get_scheduler("LCMScheduler", **NOISE_SCHEDULER_KWARGS)
+        pipe = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched).to(DEV)
+        assert pipe.use_hip_graph is True  # the default
+        pipe.use_hip_graph = use_graph
+        cn = MultiControlNetResidualsPipeline(["n0"], [0.8], use_lcm=native, controlnets=nets, device=DEV)
+        torch.manual_seed(3)
+        gen = torch.Generator(device="cpu").manual_seed(3)
+        steps, replays = [], []
+        for w in windows:
+            out = pipe(video_length=f, input_frames=None, height=8 * hw, width=8 * hw, num_inference_steps=nsteps, strength=0.5 if native else 1.0,
+                       guidance_scale=7.5 if native else 1.3, generator=gen, multicontrolnetresiduals_pipeline=cn, prompt_embeds=w["pos"],
+                       negative_prompt_embeds=w["neg"], use_lcm=native, guess_mode=native, input_latents=w["lat"],
+                       control_images={"n0": [h for h in w["hints"]]}, output_type="latent",
+                       callback=lambda i, t, l: steps.append(l.clone())).videos
+            torch.cuda.synchronize()
+            steps.append(out.clone())
+            replays.append(pipe.graph_replays)
+        if use_graph:
+            n = len(steps) // 3 - 1  # steps per window
+            assert replays == [n - 1, n, n], replays  # window 1: eager step 0 + capture; windows 2, 3: every step replays
+            assert pipe.graph_fallback_reason is None
+        runs.append(steps)
+    assert len(runs[0]) == len(runs[1]) >= 12
+    for k, (a, b) in enumerate(zip(runs[0], runs[1])):
+        assert torch.equal(a, b), f"latents differ at record {k}"
+    # the windows really differ (the refresh is not a no-op)
+    per = len(runs[0]) // 3
+    assert not torch.equal(runs[0][per - 1], runs[0][2 * per - 1])

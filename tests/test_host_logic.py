@@ -214,3 +214,23 @@ def test_every_scheduler_of_the_reference_table_is_selectable():
         assert len(s.timesteps) >= 10
     with pytest.raises(NotImplementedError):
         get_scheduler("UniPCMultistepScheduler")
+
+
+def test_predrawn_sampler_noise_equals_the_references_per_step_draws():
+    """ControlAnimationPipeline draws the sampler noise of a whole window in ONE `torch.randn` (off the per-step critical
+    path); the reference draws one tensor per step inside the loop (controlanimation_pipeline.py:1601, global CPU RNG;
+    diffusers randn_tensor with a CPU generator).  Same stream, same values -- for element counts that are multiples of 16
+    (every real latent shape: 4 x f x h x w); other shapes are drawn step by step by the pipeline."""
+    import torch
+    for shape in [(1, 4, 16, 64, 64), (1, 4, 8, 32, 32), (1, 4, 8, 8, 8), (1, 4, 16, 64, 96)]:
+        assert torch.Size(shape).numel() % 16 == 0
+        torch.manual_seed(11)
+        seq = [torch.randn(shape) for _ in range(5)]
+        torch.manual_seed(11)
+        big = torch.randn((5,) + shape)
+        assert all(torch.equal(big[i], seq[i]) for i in range(5))
+        g = torch.Generator().manual_seed(12)
+        seq = [torch.randn(shape, generator=g, dtype=torch.float32) for _ in range(3)]
+        g = torch.Generator().manual_seed(12)
+        big = torch.randn((3,) + shape, generator=g, dtype=torch.float32)
+        assert all(torch.equal(big[i], seq[i]) for i in range(3))
