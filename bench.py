@@ -64,9 +64,11 @@ def parse():
     ap.add_argument("--controlnets", type=int, default=None, help="override the config's number of ControlNets")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-config2", action="store_true",
-                    help="also time ONE full config-2 denoise step (44.6 TFLOP: ControlNet + UNet3D, fp32 oracle) on the host cores: "
-                         "about a minute of CPU work and ~40 GB of host memory; off by default so the run stays within minutes")
+    ap.add_argument("--cpu-baseline-config2", action="store_true", help=argparse.SUPPRESS)  # (old spelling: now the default)
+    ap.add_argument("--no-cpu-baseline-config2", action="store_true",
+                    help="skip the full config-2 denoise step of the fp32 oracle on the host cores (44.6 TFLOP, ControlNet + UNet3D: ~100 s "
+                         "of CPU work and ~40 GB of host memory; measured once per host and cached in the temp directory; skipped by "
+                         "itself when less than 48 GB of host memory are available)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="also print the per-shape GEMM/conv table (stderr)")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing (reported beside the metric)")
@@ -107,16 +109,31 @@ def spawn_ranks(args) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for pr in procs[1:]:
-        try:
-            pr.wait(timeout=120 if rc == 0 else 5)
-        except subprocess.TimeoutExpired:
-            pr.kill()  # exact PID of a child this parent started
-            pr.wait()
-        rc = rc or pr.returncode
-    sys.stdout.write(out0 or "")
+    # watch EVERY rank: if one dies before the rendezvous the others would sit in it until the process-group timeout
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [pr.poll() for pr in procs]
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            rc = failed[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    if rc:
+        time.sleep(1.0)
+        for r, pr in enumerate(procs):
+            if pr.poll() is None:
+                pr.kill()  # exact PID of a child this parent started
+        print(f"[bench] a rank exited with code {rc}; the remaining ranks were stopped", file=sys.stderr)
+    for pr in procs:
+        pr.wait()
+    reader.join(timeout=5)
+    sys.stdout.write("".join(b for b in buf if b))
     sys.stdout.flush()
     return rc
 
@@ -130,43 +147,36 @@ def randomize_zero_init_(model, std=0.02, seed=0):
             p.data.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
 
 
-def tile_name(m: int, n: int, k: int, conv: bool) -> str:
-    """Mirrors launch_gemm() / splitk_plan() in csrc/ca_gemm.hip (DMA path, default knobs): which k_gemm_dma
-    instantiation a launch runs.  The label is the BMxBN block tile (+ `_splitk` for the slab schedule)."""
-    def cdiv(a, b):
-        return (a + b - 1) // b
-    if k % 64:  # register-staged fallback kernel (conv_in, hint embedding)
-        wide = n % 128 == 0 and cdiv(m, 128) * cdiv(n, 128) >= 512
-        return "reg_128x128" if wide else "reg_128x64"
-    if (not conv) and k == 320 and n % 160 == 0 and n // 160 <= 32 and m >= 16384:
-        return "wres160"  # weight-resident streaming kernel (ca_gemm_wres.h): the K = 320 layers of the 64x64-latent level
-    if conv and n % 128 == 0 and cdiv(m, 128) * (n // 128) < 384 and k // 64 >= 48:
-        return "128x128_splitk"
-    if n % 320 == 0 and k // 64 >= 10:  # ping-pong 128x320 kernel where the 128x128 grid under-fills the chip (ca_gemm.hip)
-        tiles = cdiv(m, 128) * (n // 320)
-        if 128 <= tiles <= 256 or (128 <= tiles <= 512 and not conv):
-            return "pp128x320"
-    if os.environ.get("CA_GEMM_BIG") == "3" and (not conv) and n >= 5120 and k >= 640 and n % 128 == 0 and cdiv(m, 256) * (n // 128) >= 512:
-        return "256x128"  # (round-1 default; off since round 2: slower inside the step)
-    wide = n % 128 == 0 and cdiv(m, 128) * cdiv(n, 128) >= 512
-    if not wide and n % 160 == 0 and cdiv(m, 128) * (n // 160) >= 512:
-        return "128x160"
-    return "128x128" if wide else "128x64"
-
-
 def rocprof_kernel_name(family: str, dtype: str) -> str:
-    """The demangled kernel name rocprofv3 reports for a family label (profiles/*kernel_stats.csv)."""
+    """The demangled kernel name rocprofv3 reports for a family label (profiles/*kernel_stats.csv).  Family labels are
+    `<op>_<plan>` with the plan label the library itself reports for a launch (ca_gemm_plan_name / ca_conv3x3_plan_name)."""
     op, tile = family.split("_", 1)
-    if tile.startswith("reg_"):
+    if tile.startswith("reg_") or tile == "?":
         return ""
     dt = 1 if dtype == "fp16" else 0
+    mode = 1 if op == "conv3x3" else 0
     if tile == "wres160":
         return f"k_gemm_wres<{dt}>"
-    if tile == "pp128x320":
-        return f"k_gemm_pp2<{dt}, {1 if op == 'conv3x3' else 0}"
-    bm, bn = tile.replace("_splitk", "").split("x")
-    waves = "4, 2" if tile == "256x128" else ("4, 1" if tile == "128x64" else "2, 2")
-    return f"k_gemm_dma<{dt}, {bm}, {bn}, {waves}, {1 if op == 'conv3x3' else 0}, "
+    if tile.startswith("pp128x320"):
+        return f"k_gemm_pp2<{dt}, {mode}"
+    if tile == "ps128x320":
+        return f"k_gemm_ps<{dt}, {mode}"
+    base = tile.split("_")[0]
+    bm, bn = base.split("x")
+    waves = "4, 1" if base == "128x64" else "2, 2"
+    nbuf = 2 if tile.endswith("_db") else 1
+    return f"k_gemm_dma<{dt}, {bm}, {bn}, {waves}, {mode}, {nbuf}, "
+
+
+def kernel_display_name(family: str) -> str:
+    tile = family.split("_", 1)[1]
+    if tile == "wres160":
+        return f"k_gemm_wres<{family}>"
+    if tile.startswith("pp128x320"):
+        return f"k_gemm_pp2<{family}>"
+    if tile == "ps128x320":
+        return f"k_gemm_ps<{family}>"
+    return f"k_gemm_dma<{family}>"
 
 
 PMC_SUMMARIES = ("round2_pmc_traffic.json", "round1_pmc_traffic.json")
@@ -215,27 +225,31 @@ class KernelTimer:
             if not timer.enabled:
                 return gemm0(a, w, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            K._plan_sink = sink = []
             s.record()
             out = gemm0(a, w, **kw)
             e.record()
+            K._plan_sink = None
             m, n, k = a.shape[0], w.shape[0], w.shape[1]
             # algorithmic bytes: every operand once (A, W, C, residual), 2 B per element
             nb = 2.0 * (m * k + n * k + m * (n // 2 if kw.get("geglu") else n) + (m * n if kw.get("residual") is not None else 0))
             timer.bytes[id(s)] = nb
-            timer.records.append((f"gemm_{tile_name(m, n, k, False)}", 2.0 * m * n * k, s, e, (m, n, k)))
+            timer.records.append((f"gemm_{sink[-1] if sink else '?'}", 2.0 * m * n * k, s, e, (m, n, k)))
             return out
 
         def conv3x3(x, w, **kw):
             if not timer.enabled:
                 return conv0(x, w, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            K._plan_sink = sink = []
             s.record()
             out = conv0(x, w, **kw)
             e.record()
+            K._plan_sink = None
             n = w.shape[0]
             mrows = out.shape[0] * out.shape[1] * out.shape[2]
             timer.bytes[id(s)] = 2.0 * (x.numel() + (kw["x2"].numel() if kw.get("x2") is not None else 0) + w.numel() + out.numel())
-            timer.records.append((f"conv3x3_{tile_name(mrows, n, 9 * w.shape[3], True)}", 2.0 * mrows * n * 9 * w.shape[3], s, e,
+            timer.records.append((f"conv3x3_{sink[-1] if sink else '?'}", 2.0 * mrows * n * 9 * w.shape[3], s, e,
                                   (mrows, n, 9 * w.shape[3])))
             return out
 
@@ -355,6 +369,35 @@ def cpu_baseline_config2(threads: int):
         dt = time.time() - t0
     return {"sec_per_step": dt, "tflops": 44.6 / dt, "frames_per_sec": 16.0 / (20 * dt), "cores": threads,
             "sample": "1 oracle denoise step of BASELINE config 2 (ControlNet B=32 + UNet3D b=2 f=16 64x64 latents, fp32)"}
+
+
+def cpu_baseline_config2_cached(threads: int):
+    """cpu_baseline_config2 once per host and core count (the file lives in the temp directory), None when the host has
+    too little free memory for the fp32 oracle at this size."""
+    import socket
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"controlanimate_amd_cpu_config2_{socket.gethostname()}_{threads}.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        d["cached"] = True
+        return d
+    except (OSError, ValueError):
+        pass
+    try:
+        avail_kb = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:"))
+    except (OSError, StopIteration, ValueError):
+        avail_kb = 0
+    if avail_kb < 48 * 1024 * 1024:
+        return {"skipped": "less than 48 GB of host memory available (%d MB)" % (avail_kb // 1024)}
+    d = cpu_baseline_config2(threads)
+    try:
+        with open(path, "w") as fh:
+            json.dump(d, fh)
+    except OSError:
+        pass
+    d["cached"] = False
+    return d
 
 
 def cpu_baseline(threads: int):
@@ -486,118 +529,107 @@ def main():
     neg = (torch.randn(1, L, 768, generator=g) * 0.5).to(device)
     guidance = wl["guidance"]
     rep = 2 if guidance > 1.0 else 1
-    prompt = torch.cat([neg, pos]).contiguous() if rep == 2 else pos.contiguous()
     cn_single = wl["guess_mode"] or rep == 1          # ControlNet input selection (:811-813)
-    cn_prompt = pos.contiguous() if cn_single else prompt
     cn = None
+    hints_dev = None
     if nets:
         cn = MultiControlNetResidualsPipeline([f"synthetic-canny-{i}" for i in range(len(nets))], [1.0] * len(nets), use_lcm=False,
                                               controlnets=nets, device=device)
-        hints = torch.rand(f, 3, wl["height"], wl["width"], generator=g)
-        cn.prep_control_images([h for h in hints], do_classifier_free_guidance=rep == 2, guess_mode=wl["guess_mode"])
+        hints_dev = [h for h in torch.rand(f, 3, wl["height"], wl["width"], generator=g).to(device)]  # resident: inputs are in HBM
     sched = get_scheduler(wl["scheduler"], **NOISE_SCHEDULER_KWARGS)
-    sched.set_timesteps(steps_per_window)
-    cpad = unet.conv_in.cin_pad
-    noise_dev = torch.randn(1, 4, f, lh, lw, generator=g).to(device)
 
-    state = {"latents": latents * float(getattr(sched, "init_noise_sigma", 1.0))}
-    x_static = torch.empty((rep * f, lh, lw, cpad), device=device, dtype=dtype)
-    t_static = torch.zeros(1, device=device, dtype=torch.float32)
-    graph_state = {"graph": None, "eps": None}
-    overlap = {"on": not args.no_overlap}
-    window_refresh = {"gemms": 0}
+    # THE PRODUCT'S LOOP: every step below is an iteration of ControlAnimationPipeline.__call__ (the reference's
+    # controlanimation_pipeline.py:790-855) -- latents in, latents out, no VAE / text encoder (output_type="latent",
+    # prompt embeddings given).  One call = steps [lo, hi) of one window (`step_range`, the pipeline's own hook); a call that
+    # starts at step 0 is a window start and does the window's work: prompt embeddings and control frames copied into the
+    # tensors the captured hipGraph reads, text / IP K/V and hint embeddings recomputed in place, the sampler noise of the
+    # window drawn on the host and uploaded asynchronously.  The hipGraph is the pipeline's default (use_hip_graph): captured
+    # once in the first window, replayed for every later step of every later window.
+    from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
+    pipe = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched).to(device)
+    pipe.use_hip_graph = not args.no_graph
+    pipe.overlap_controlnet = not args.no_overlap
+    lat0 = latents * float(getattr(sched, "init_noise_sigma", 1.0))
+    gen = torch.Generator(device="cpu").manual_seed(4321)
+    state = {"latents": lat0}
+    step_events = []
 
-    def model_eps(t):
-        """ControlNet residuals + UNet3D eps for the contents of x_static at (device) timestep t."""
-        down = mid = None
-        if cn is not None:
-            x_cn = x_static[:f] if (cn_single and rep == 2) else x_static
-            twice = rep == 2 and not cn_single  # (as ControlAnimationPipeline.__call__: x_static repeats one latent tensor)
-            if overlap["on"]:  # ControlNet beside the UNet encoder on a second stream (as the pipeline does)
-                down = cn.residuals_nhwc_async(x_cn, t, cn_prompt, wl["guess_mode"], cfg_identical_halves=twice)
-            else:
-                down, mid = cn.residuals_nhwc(x_cn, t, cn_prompt, wl["guess_mode"], cfg_identical_halves=twice)
-        return unet.forward_nhwc(x_static, rep, f, t, prompt, down, mid, cfg_identical_halves=rep == 2)
+    def run_steps(lo, hi, record_events=False):
+        def cb(i, t, lat):
+            if record_events:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                step_events.append(e)
+        out = pipe(video_length=f, input_frames=None, height=wl["height"], width=wl["width"], num_inference_steps=steps_per_window,
+                   strength=1.0, guidance_scale=guidance, generator=gen, latents=lat0, prompt_embeds=pos, negative_prompt_embeds=neg,
+                   multicontrolnetresiduals_pipeline=cn, control_images=hints_dev, use_lcm=False, guess_mode=wl["guess_mode"],
+                   output_type="latent", step_range=(lo, hi), callback=cb).videos
+        state["latents"] = out
+        state["replays"] = state.get("replays", 0) + int(pipe.graph_replays)
+        return out
 
-    def step(i):
-        idx = i % steps_per_window
-        if idx == 0 and graph_state["graph"] is not None:
-            # a new window: its per-window work (hint embedding of the control frames, text / IP K/V of every
-            # cross-attention site) is redone here, in place, inside the timed region -- the graph replays only reuse it
-            # (eager steps redo nothing: the pipeline's first eager step of a window fills these caches the same way)
-            window_refresh["gemms"] = unet.refresh_window_caches() + sum(n.refresh_window_caches() for n in nets)
-        K.latents_to_nhwc(state["latents"], cpad, rep, sched.input_scale(idx), dtype, out=x_static)
-        if graph_state["graph"] is not None:
-            t_static.fill_(float(sched.timesteps[idx]))
-            graph_state["graph"].replay()
-            eps = graph_state["eps"]
-        else:
-            eps = model_eps(sched.timesteps[idx])
-        coef, clip = sched.coefficients(idx)
-        state["latents"], _ = K.cfg_scheduler_step(eps, rep, guidance if rep == 2 else 1.0, state["latents"],
-                                                   noise_dev if sched.needs_noise else None, coef, clip)
-        if idx == steps_per_window - 1:
-            state["latents"] = latents * float(getattr(sched, "init_noise_sigma", 1.0))  # next window
-
-    def capture_graph():
-        model_eps(t_static)  # warm: prompt K/V and hint-embedding caches, allocator pools
-        torch.cuda.synchronize()
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
-            graph_state["eps"] = model_eps(t_static)
-        graph_state["graph"] = gr
+    def run_k_steps(k, record_events=False):
+        """k consecutive loop iterations starting AT a window start: ceil(k / steps_per_window) calls."""
+        done = 0
+        while done < k:
+            n = min(k - done, steps_per_window)
+            if record_events:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                step_events.append(("start", e))
+            run_steps(0, n, record_events)
+            done += n
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    use_graph = not args.no_graph
-    if use_graph:
-        try:
-            capture_graph()
-        except Exception as exc:  # keep measuring: eager launches are the same work
-            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
-            graph_state["graph"], use_graph = None, False
-            torch.cuda.synchronize()
-    # The timed region starts AT a window start (step index 0 of a window): the warm-up steps are the last ones of the
-    # previous window.  K timed steps therefore contain ceil(K / steps_per_window) window starts with their per-window
-    # work (one per 10 steps at the default K = 10: twice the rate of a 20-step window, i.e. never under-counted).
-    i0 = (-args.warmup) % steps_per_window
-    for i in range(args.warmup):
-        step(i0 + i)
+    # first window, untimed: the eager step 0 (fills every cache, warms the allocator) and the capture at step 1
+    run_steps(0, steps_per_window)
+    torch.cuda.synchronize()
+    use_graph = bool(pipe.use_hip_graph) and pipe.graph_fallback_reason is None and pipe._graph_state is not None and pipe._graph_state["graph"] is not None
+    if pipe.use_hip_graph and not use_graph:
+        print(f"[bench] hipGraph capture failed ({pipe.graph_fallback_reason}); running eagerly", file=sys.stderr)
+    # The timed region starts AT a window start: the warm-up steps are the last ones of the previous window.  K timed steps
+    # therefore contain ceil(K / steps_per_window) window starts with their per-window work (one per 10 steps at the default
+    # K = 10: twice the rate of a 20-step window, i.e. never under-counted).
+    if args.warmup > 0:
+        w = min(args.warmup, steps_per_window)
+        run_steps(steps_per_window - w, steps_per_window)
     torch.cuda.synchronize()
     barrier()
     timer.enabled = False  # per-launch HIP events cost ~7% of a step: they are taken in a second pass
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    replays_before = state.get("replays", 0)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        step(i0 + args.warmup + i)
-        ev[i][1].record()
+    run_k_steps(args.steps, record_events=True)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    step_ms, prev = [], None
+    for e in step_events:
+        if isinstance(e, tuple):
+            prev = e[1]
+        else:
+            step_ms.append(prev.elapsed_time(e))
+            prev = e
+    step_ms.sort()
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
-    timer.enabled = False
+    replays_timed = state.get("replays", 0) - replays_before
     roof_elapsed = elapsed
     if not args.no_roofline:
-        # Instrumented pass: the SAME launches, eager, with a HIP-event pair around every GEMM/conv launch
-        # (events on the launch stream).  Kept out of the headline timing because ~3000 event records
-        # per step slow the step by ~7% (84 -> 90 ms); the per-kernel durations it reports agree with
-        # the rocprofv3 --kernel-trace averages in profiles/.
-        gr, graph_state["graph"] = graph_state["graph"], None
-        overlap["on"] = False  # one stream: a launch's event pair then times that kernel alone
+        # Instrumented pass: the SAME calls, eager, one stream, with a HIP-event pair around every GEMM/conv launch (events
+        # on the launch stream).  Kept out of the headline timing because ~3000 event records per step slow the step by
+        # ~7%; the per-kernel durations it reports agree with the rocprofv3 --kernel-trace averages in profiles/.
+        pipe.use_hip_graph, pipe.overlap_controlnet = False, False
         timer.enabled = True
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(min(args.steps, 5)):
-            step(i)
+        run_steps(0, min(args.steps, 5, steps_per_window))
         torch.cuda.synchronize()
         roof_elapsed = time.perf_counter() - t1
         timer.enabled = False
-        graph_state["graph"] = gr
+        pipe.use_hip_graph, pipe.overlap_controlnet = not args.no_graph, not args.no_overlap
     vae_ms = None
     if not args.no_vae and world == 1:  # single-GPU runs only: the other ranks of a scaling run must not wait for it
         vae_ms = time_vae(wl, device, dtype)
@@ -636,11 +668,16 @@ def main():
         # contributes frame_count - overlap_length NEW frames; equal to `value` when the config has no overlap
         "frames_per_sec_steady_state": round(world * f_new / (steps_per_window * sec_per_step), 4),
         "window_starts_in_timed_region": (args.steps + steps_per_window - 1) // steps_per_window,
-        "per_window_work_in_timed_region": ("hint embedding + text/IP K/V recomputed in place at every window start "
-                                            f"({window_refresh['gemms']} launches groups); the timed region begins at a window start" if use_graph else
+        "timed_through": "ControlAnimationPipeline.__call__ (latents in / latents out, step_range windows)",
+        "per_window_work_in_timed_region": ("prompt / control-frame rebind, hint embedding + text/IP K/V recomputed in place, sampler noise drawn and "
+                                            "uploaded, at every window start; the timed region begins at a window start" if use_graph else
                                             "eager run: nothing is cached outside the timed region except across the steps of a window"),
+        "graph_replays_in_timed_region": int(replays_timed) if use_graph else 0,
         "step_algorithmic_tflop": round(step_tflop, 2),
-        "step_mfma_frac": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
+        # utilisation of the dense MFMA peak by the work that was EXECUTED (the shared CFG prefix runs once: see below);
+        # `step_mfma_frac_algorithmic` divides the reference's count (both halves) by the same time and overstates it
+        "step_mfma_frac": round((step_tflop - shared_tflop) / sec_per_step / PEAK_MFMA_TFLOPS, 4),
+        "step_mfma_frac_algorithmic": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
         # classifier-free guidance repeats ONE latent tensor for both batch halves: up to the first cross-attention (conv_in,
         # first resnet, first transformer's GroupNorm / proj_in / 4096-token self-attention) the halves are the same
         # computation, which runs once (bit-identical results: tests/test_workload_configs_gpu.py; CA_CFG_SHARED=0 disables).  The
@@ -662,7 +699,7 @@ def main():
             d = agg[dom]
             rname = rocprof_kernel_name(dom, args.dtype)
             traffic, traffic_src = pmc_traffic(rname, "config%d" % args.config if not custom else "custom", args.dtype)
-            kname = f"k_gemm_wres<{dom}>" if dom.endswith("wres160") else (f"k_gemm_pp2<{dom}>" if dom.endswith("pp128x320") else f"k_gemm_dma<{dom}>")
+            kname = kernel_display_name(dom)
             # which roof bounds this instantiation's launch mix: algorithmic FLOP per algorithmic byte (every operand
             # once) against the machine balance 2500 TFLOP/s : 8 TB/s = 312 FLOP/B
             gbps = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
@@ -681,7 +718,12 @@ def main():
                                "flop_per_byte": round(d["flops"] / d["bytes"], 1) if d["bytes"] else None,
                                "share_of_step_time": round(d["ms"] * 1e-3 / roof_elapsed, 4),
                                "measured": "HIP events around every launch, instrumented pass of %d steps after the timed region" % min(args.steps, 5)}
+            # per family: algorithmic FLOPs and bytes (every operand once) per launch, so that any family's traffic ratio can
+            # be recomputed against the PMC summary in profiles/, not only the dominant one's
             out["kernel_family"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2),
+                                        "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"], 1),
+                                        "algorithmic_gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0,
+                                        "rocprof_name": rocprof_kernel_name(k, args.dtype) or None,
                                         "time_share": round(v["ms"] * 1e-3 / roof_elapsed, 4)} for k, v in sorted(agg.items())}
     if args.shapes and rank == 0 and not args.no_roofline:
         for row in timer.by_shape():
@@ -690,8 +732,8 @@ def main():
             print(row, file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(usable_cores())
-        if args.cpu_baseline_config2:
-            out["cpu_baseline"]["config2_step"] = cpu_baseline_config2(usable_cores())
+        if not args.no_cpu_baseline_config2:
+            out["cpu_baseline"]["config2_step"] = cpu_baseline_config2_cached(usable_cores())
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

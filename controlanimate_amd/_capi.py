@@ -85,6 +85,7 @@ class AttnArgs(C.Structure):
         ("nq", C.c_int32), ("nk", C.c_int32),
         ("scale", C.c_float), ("out_scale", C.c_float),
         ("accumulate", C.c_int32), ("dtype", C.c_int32), ("causal", C.c_int32),
+        ("key_mask", C.c_void_p), ("key_mask_stride", C.c_int64),
     ]
 
 

@@ -55,10 +55,10 @@ class CLIPEncoderLayer(nn.Module):
         self.mlp = _MLP(c, inter)
         self.layer_norm2 = HipLayerNorm(c, eps)
 
-    def run(self, x: torch.Tensor, batch: int, tokens: int, causal: bool) -> torch.Tensor:
+    def run(self, x: torch.Tensor, batch: int, tokens: int, causal: bool, key_mask=None) -> torch.Tensor:
         a = self.self_attn
         qkv = K.gemm(self.layer_norm1.run(x), a.wqkv.t, bias=a.bqkv.t)
-        o = K.attention_spatial(qkv, batch, tokens, self.heads, causal=causal)
+        o = K.attention_spatial(qkv, batch, tokens, self.heads, causal=causal, key_mask=key_mask)
         x = a.out_proj.run(o, residual=x)
         h = self.mlp.fc1.run(self.layer_norm2.run(x), act=self.act)
         return self.mlp.fc2.run(h, residual=x)
@@ -192,8 +192,11 @@ class CLIPTextModel(_PackedModel):
     @torch.no_grad()
     def forward(self, input_ids: torch.Tensor, attention_mask=None, position_ids=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None):
+        # attention_mask [B, L] (1 = attend): transformers adds it, expanded to [B,1,1,L], to the causal mask -- a masked token
+        # is invisible as a KEY to every query.  Compel's default down-weighting (DownweightMode.MASK) passes one.
+        key_mask = None
         if attention_mask is not None and not bool(torch.as_tensor(attention_mask).bool().all()):
-            raise NotImplementedError("padding masks are not supported (the reference's Compel call passes none)")
+            key_mask = torch.as_tensor(attention_mask).bool()
         if position_ids is not None:
             raise NotImplementedError("custom position_ids")
         dev = input_ids.device if input_ids.is_cuda else self.device
@@ -206,8 +209,12 @@ class CLIPTextModel(_PackedModel):
         x = tm.embeddings.token_embedding.weight[ids] + tm.embeddings.position_embedding.weight[:n]
         x = x.to(self.act_dtype).reshape(b * n, -1).contiguous()
         hidden = [x.view(b, n, -1)] if output_hidden_states else None
+        if key_mask is not None:
+            if tuple(key_mask.shape) != (b, n):
+                raise ValueError(f"attention_mask {tuple(key_mask.shape)} does not match input_ids {(b, n)}")
+            key_mask = key_mask.to(device=dev, dtype=torch.uint8).contiguous()
         for layer in tm.encoder.layers:
-            x = layer.run(x, b, n, causal=True)
+            x = layer.run(x, b, n, causal=True, key_mask=key_mask)
             if hidden is not None:
                 hidden.append(x.view(b, n, -1))
         last = tm.final_layer_norm.run(x).view(b, n, -1)

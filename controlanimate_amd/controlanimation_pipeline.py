@@ -51,6 +51,7 @@ class ControlAnimationPipeline:
         # logged and the window runs eagerly (`graph_fallback_reason`).
         self.use_hip_graph = True
         self._graph_state = None
+        self._noise_state = None
         if scheduler is None:  # native LCM (reference :95-101)
             scheduler = LCMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", prediction_type="epsilon")
         self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
@@ -367,11 +368,27 @@ class ControlAnimationPipeline:
         def draw_all_noise():
             n_steps, shape = len(timesteps), tuple(latents.shape)
             gen = None if native_noise else generator
+            st = self._noise_state
+            need = (n_steps,) + shape
+            if st is None or tuple(st["host"].shape) != need or st["dev"].device != device:
+                host = torch.empty(need, dtype=torch.float32)
+                try:
+                    host = host.pin_memory()  # the upload is then asynchronous: queued behind step 0, the CPU moves on
+                except RuntimeError:
+                    pass
+                st = self._noise_state = {"host": host, "dev": torch.empty(need, device=device, dtype=torch.float32), "done": None}
+            if st["done"] is not None:
+                st["done"].synchronize()  # (the previous window's upload has long finished)
             if latents.numel() % 16 == 0:
-                big = torch.randn((n_steps,) + shape, generator=gen, dtype=torch.float32)
+                torch.randn(need, generator=gen, dtype=torch.float32, out=st["host"])
             else:
-                big = torch.stack([torch.randn(shape, generator=gen, dtype=torch.float32) for _ in range(n_steps)])
-            return big.to(device)
+                for k_ in range(n_steps):
+                    torch.randn(shape, generator=gen, dtype=torch.float32, out=st["host"][k_])
+            st["dev"].copy_(st["host"], non_blocking=True)
+            if device.type == "cuda":
+                st["done"] = torch.cuda.Event()
+                st["done"].record()
+            return st["dev"]
 
         for i, t in enumerate(timesteps):
             idx = first + i

@@ -40,6 +40,8 @@ struct AttnKParams {
   int accumulate;
   int sum_row;  // 1: V^T row `head_dim` is all ones, so the PV MFMA also produces the softmax row sums
   int causal;   // 1: key j is visible to query i only if j <= i (CLIP text encoder); generic kernel only
+  const unsigned char* key_mask;  // per (batch, key): 0 = invisible (ca_attn_args.key_mask); generic kernel only
+  int64_t key_mask_stride;
 };
 
 template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool PF>
@@ -229,14 +231,16 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
     bool grow = false;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      if (TAIL) {  // (also every tile of a causal launch)
+      if (TAIL) {  // (also every tile of a causal / key-masked launch)
         const int qlim = p.causal ? q0 + t * 16 + l15 : 0x7fffffff;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kv0 + kt * 16 + g * 4 + r;
-            if (key >= p.nk || key > qlim) sacc[t][kt][r] = -INFINITY;
+            bool hide = key >= p.nk || key > qlim;
+            if (p.key_mask && key < p.nk) hide |= p.key_mask[(int64_t)z * p.key_mask_stride + key] == 0;
+            if (hide) sacc[t][kt][r] = -INFINITY;
           }
       }
       float m = vmax3(sacc[t][0][0], sacc[t][0][1], sacc[t][0][2]);
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
   {
     const int nfull = p.nk / KB;
     int iter = 0;
-    if (p.causal) {
+    if (p.causal || p.key_mask) {
       for (; iter < nfull; ++iter) tile_body(iter * KB, iter, BoolC<true>{});
     } else {
       for (; iter < nfull; ++iter) tile_body(iter * KB, iter, BoolC<false>{});
@@ -372,7 +376,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
 // of the QK^T MFMA ready-made.  Q is pre-multiplied by scale*log2(e) (fp32 multiply, one rounding), column head_dim of
 // every K row holds 1 and the matching k-slot of the Q fragment holds -mref (the quantised reference maximum of that
 // query), so S' = s*scale*log2(e) - mref and p = 2^S' with no per-score VALU besides the v_exp itself.
-template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool SR, bool FOLD>
+// K16 (round 3): head dims of 32 .. 44 (SD1.5's 40) needed a second, mostly empty 32-deep chunk for d = 32 .. 39 and the FOLD
+// column -- 37% of the QK^T MFMA work multiplied zeros.  With K16 the chunk behind the DK32 full ones is 16 deep and runs
+// on v_mfma_f32_16x16x16 (a lane holds k = 4g .. 4g+3: 8-byte fragment reads): QK^T costs 48 instead of 64 columns.
+template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool SR, bool FOLD, bool K16 = false>
 __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   constexpr int ROW = 64;                 // LDS row length (elements): head_dim <= 64
   constexpr int KT = KB / 16, KC = KB / 32;
@@ -423,6 +430,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   }
 
   u32x4 qf[QT][DK32];
+  u32x2 qf16[QT];  // K16: d = 32 * DK32 + 4g .. +3
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int qi = q0 + t * 16 + l15;
@@ -438,10 +446,27 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
         qf[t][kc] = pack8<DT>(f);
       }
     }
+    qf16[t] = (u32x2){0u, 0u};
+    if (K16) {
+      const int d = DK32 * 32 + g * 4;
+      if (qi < p.nq && d < p.head_dim) qf16[t] = *reinterpret_cast<const u32x2*>(qp + (int64_t)qi * p.q_row + d);
+      if (FOLD) {
+        const float f0 = Elem<DT>::to_f((u16)(qf16[t][0] & 0xffffu)) * p.scale_log2, f1 = Elem<DT>::to_f((u16)(qf16[t][0] >> 16)) * p.scale_log2;
+        const float f2 = Elem<DT>::to_f((u16)(qf16[t][1] & 0xffffu)) * p.scale_log2, f3 = Elem<DT>::to_f((u16)(qf16[t][1] >> 16)) * p.scale_log2;
+        qf16[t][0] = pack2<DT>(f0, f1);
+        qf16[t][1] = pack2<DT>(f2, f3);
+      }
+    }
   }
   // FOLD: the lanes of row group fold_g hold k-slot head_dim of k32 chunk fold_kc, element 0 of their fragment
+  // (K16 and head_dim >= 32 * DK32: the 16-deep chunk's row group (head_dim - 32 * DK32) / 4, element 0)
   const int fold_kc = p.head_dim >> 5, fold_g = (p.head_dim & 31) >> 3;
+  const int fold_g16 = (p.head_dim - DK32 * 32) >> 2;
   auto set_qref = [&](int t, float mnew) {
+    if (K16 && p.head_dim >= DK32 * 32) {
+      if (g == fold_g16) qf16[t][0] = (qf16[t][0] & 0xffff0000u) | (unsigned)Elem<DT>::from_f(-mnew);
+      return;
+    }
 #pragma unroll
     for (int kc = 0; kc < DK32; ++kc)
       if (kc == fold_kc && g == fold_g) qf[t][kc][0] = (qf[t][kc][0] & 0xffff0000u) | (unsigned)Elem<DT>::from_f(-mnew);
@@ -510,6 +535,15 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
         const u32x4 kf = ld16(Ks + row * ROW + (((kc * 4 + g) ^ ((row >> 1) & 7)) << 3));
 #pragma unroll
         for (int t = 0; t < QT; ++t) sacc[t][kt] = Elem<DT>::mfma(kf, qf[t][kc], sacc[t][kt]);
+      }
+    }
+    if (K16) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int row = kt * 16 + l15;
+        const u32x2 kf = *reinterpret_cast<const u32x2*>(Ks + row * ROW + (((DK32 * 4 + (g >> 1)) ^ ((row >> 1) & 7)) << 3) + (g & 1) * 4);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) sacc[t][kt] = Elem<DT>::mfma16(kf, qf16[t], sacc[t][kt]);
       }
     }
 
@@ -671,10 +705,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
 template <int DT, int DK32, int DV16>
 void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
   AttnKParams p = p0;
-  if (p.nq <= 16 && p.nk <= 32 && !p.causal) {
+  if (p.nq <= 16 && p.nk <= 32 && !p.causal && !p.key_mask) {
     p.qblocks = 1;
     hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 1, 1, 32, false>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
-  } else if (p.nq <= 32 && p.nk <= 32 && !p.causal) {
+  } else if (p.nq <= 32 && p.nk <= 32 && !p.causal && !p.key_mask) {
     p.qblocks = 1;
     hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 1, 32, false>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
   } else {
@@ -683,13 +717,18 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
     p.qblocks = ceil_div_i(p.nq, 128);
     const dim3 grid((unsigned)(p.qblocks * p.batches * p.heads));
     static const int dma_env = CA_KNOB("CA_ATTN_DMA", 1);
-    if (DK32 <= 2 && dma_env && !p.causal && p.nk >= 256 && p.k_row % 8 == 0 &&
+    if (DK32 <= 2 && dma_env && !p.causal && !p.key_mask && p.nk >= 256 && p.k_row % 8 == 0 &&
         ((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2 < (int64_t)0xFFFFFF00ll) {
       // the ones column needs a free, 16-byte aligned pad chunk inside the last 16-wide dv tile
       static const int sr_env = CA_KNOB("CA_ATTN_SR", 1);
       const bool sr = sr_env && p.head_dim % 8 == 0 && p.head_dim / 16 == DV16 - 1;
       static const int fold_env = CA_KNOB("CA_ATTN_FOLD", 1);
       const bool fold = sr && fold_env && p.head_dim + 8 <= DK32 * 32;
+      static const int k16_env = CA_KNOB("CA_ATTN_K16", 1);
+      if (fold && k16_env && DK32 == 2 && DV16 == 3 && p.head_dim >= 32 && p.head_dim <= 44) {  // head_dim 40: 32 + 16 instead of 64 deep
+        hipLaunchKernelGGL((k_attn_dma<DT, 1, 3, 2, 4, 64, true, true, true>), grid, dim3(256), 0, st, p);
+        return;
+      }
       if (fold) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, true>), grid, dim3(256), 0, st, p);
       else if (sr) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, false>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, false, false>), grid, dim3(256), 0, st, p);
@@ -759,6 +798,9 @@ extern "C" int ca_attention(const ca_attn_args* a, void* stream) {
   p.accumulate = a->accumulate;
   p.causal = a->causal ? 1 : 0;
   CA_REQUIRE(!a->causal || a->nq == a->nk, "ca_attention: causal needs nq == nk");
+  p.key_mask = a->key_mask;
+  p.key_mask_stride = a->key_mask_stride;
+  CA_REQUIRE(!a->key_mask || a->key_mask_stride >= a->nk, "ca_attention: key_mask_stride=%lld < nk", (long long)a->key_mask_stride);
   {
     const int d = a->head_dim;
     const int dvp = d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : d <= 80 ? 80 : d <= 128 ? 128 : 160;

@@ -56,6 +56,11 @@ struct Elem<CA_BF16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
+  // 16x16x16: a lane holds k = 4*(lane>>4) .. +3 (8 bytes) of row / column lane&15
+  static __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
 };
 
 template <>
@@ -68,6 +73,10 @@ struct Elem<CA_F16> {
   static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
                                                   __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
   }
 };
 

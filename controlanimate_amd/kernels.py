@@ -247,10 +247,13 @@ def row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
 def attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, *, q_off: int, k_off: int,
                   v_off: int, o_off: int, q_strides, o_strides, k_strides, inner_count: int, kv_inner_count: int,
                   kv_div: int, batches: int, heads: int, head_dim: int, nq: int, nk: int, scale: float,
-                  out_scale: float = 1.0, accumulate: bool = False, kv_mod: int = 0, causal: bool = False) -> None:
+                  out_scale: float = 1.0, accumulate: bool = False, kv_mod: int = 0, causal: bool = False,
+                  key_mask: Optional[torch.Tensor] = None) -> None:
     """Direct mapping of ca_attention. *_off are element offsets into the given storage tensors;
-    *_strides = (outer, inner, row) in elements."""
-    _req_cuda(q, k, v, o)
+    *_strides = (outer, inner, row) in elements.  key_mask: uint8 [batches, nk], 0 = key invisible (ca_attn_args.key_mask)."""
+    _req_cuda(q, k, v, o, key_mask)
+    if key_mask is not None:
+        assert key_mask.dtype == torch.uint8 and key_mask.dim() == 2 and key_mask.shape == (batches, nk) and key_mask.stride(1) == 1
     es = q.element_size()
     args = AttnArgs(q=q.data_ptr() + q_off * es, k=k.data_ptr() + k_off * es, v=v.data_ptr() + v_off * es,
                     o=o.data_ptr() + o_off * es,
@@ -259,12 +262,15 @@ def attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Te
                     k_outer=k_strides[0], k_inner=k_strides[1], k_row=k_strides[2],
                     inner_count=inner_count, kv_inner_count=kv_inner_count, kv_div=kv_div,
                     kv_mod=kv_mod if kv_mod > 0 else batches, batches=batches, heads=heads, head_dim=head_dim, nq=nq, nk=nk, scale=scale, out_scale=out_scale,
-                    accumulate=int(accumulate), dtype=dt_code(q.dtype), causal=int(causal))
+                    accumulate=int(accumulate), dtype=dt_code(q.dtype), causal=int(causal),
+                    key_mask=_p(key_mask), key_mask_stride=key_mask.stride(0) if key_mask is not None else 0)
     check(lib().ca_attention(C.byref(args), _stream()), "ca_attention")
 
 
-def attention_spatial(qkv: torch.Tensor, images: int, tokens: int, heads: int, causal: bool = False) -> torch.Tensor:
-    """Self-attention per image. qkv: [images*tokens, 3C] (q | k | v); returns [images*tokens, C]."""
+def attention_spatial(qkv: torch.Tensor, images: int, tokens: int, heads: int, causal: bool = False,
+                      key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Self-attention per image. qkv: [images*tokens, 3C] (q | k | v); returns [images*tokens, C].
+    key_mask: uint8 [images, tokens], 0 = that token is invisible as a key (transformers' attention_mask)."""
     c = qkv.shape[1] // 3
     d = c // heads
     o = torch.empty((images * tokens, c), device=qkv.device, dtype=qkv.dtype)
@@ -272,7 +278,7 @@ def attention_spatial(qkv: torch.Tensor, images: int, tokens: int, heads: int, c
     attention_raw(qkv, qkv, qkv, o, q_off=0, k_off=c, v_off=2 * c, o_off=0,
                   q_strides=(tokens * ld, 0, ld), o_strides=(tokens * c, 0, c), k_strides=(tokens * ld, 0, ld),
                   inner_count=1, kv_inner_count=1, kv_div=1, batches=images, heads=heads, head_dim=d,
-                  nq=tokens, nk=tokens, scale=d ** -0.5, causal=causal)
+                  nq=tokens, nk=tokens, scale=d ** -0.5, causal=causal, key_mask=key_mask)
     return o
 
 

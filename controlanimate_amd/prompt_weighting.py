@@ -12,10 +12,12 @@ to compare with):
              with the pad token; a token carries its fragment's weight, BOS / EOS / padding carry 1.
   weights    z = E(tokens), z0 = E(empty prompt):  weighted = z0 + (z - z0) * w_token   (so w = 1 everywhere is the plain
              encoding, bit for bit).
-  w < 1      per down-weighted fragment a second embedding of the prompt WITHOUT that fragment (built the same way) is
-             blended in with weight tan((1 - w) * pi / 2) against 1 for the base embedding, normalised -- Compel's
-             `DownweightMode.REMOVE`.  (2.0.2's default masks the fragment's tokens in the text encoder's attention
-             instead of removing them; the HIP CLIP encoder has the causal mask only, so the removal variant is used.)
+  w < 1      per down-weighted fragment a second embedding of the prompt "without" that fragment is blended in with weight
+             tan((1 - w) * pi / 2) against 1 for the base embedding, normalised.  "Without" = Compel 2.0.2's default
+             `DownweightMode.MASK` (round 3): the SAME token ids, with the fragment's token positions zeroed in the text
+             encoder's attention mask (hidden as keys under the causal mask: ca_attention's key mask, ABI v7), weighted per
+             token like the base embedding; `downweight_mode="remove"` re-tokenises the prompt without the fragment instead
+             (`DownweightMode.REMOVE`).
 
 Host-side string processing + a handful of text-encoder calls per window; the encoder itself is the HIP CLIPTextModel.
 """
@@ -116,8 +118,11 @@ def parse_prompt(text: str) -> List[Fragment]:
 class Compel:
     """`Compel(tokenizer=..., text_encoder=...)(prompt) -> [1, 77, dim]` (the reference's call, :133-135)."""
 
-    def __init__(self, tokenizer, text_encoder: Callable, truncate_long_prompts: bool = True, device=None):
+    def __init__(self, tokenizer, text_encoder: Callable, truncate_long_prompts: bool = True, device=None, downweight_mode: str = "mask"):
         self.tokenizer, self.text_encoder, self.device = tokenizer, text_encoder, device
+        if downweight_mode not in ("mask", "remove"):
+            raise ValueError("downweight_mode must be 'mask' (Compel's default) or 'remove'")
+        self.downweight_mode = downweight_mode
         if not truncate_long_prompts:
             raise NotImplementedError("only truncate_long_prompts=True (the reference's default) is implemented")
         self.max_length = int(getattr(tokenizer, "model_max_length", 77))
@@ -128,15 +133,19 @@ class Compel:
         ids = list(ids[0]) if ids and isinstance(ids[0], (list, tuple)) else list(ids)
         return ids[1:-1]  # without BOS / EOS
 
-    def token_ids_and_weights(self, fragments: Sequence[Fragment]) -> Tuple[torch.Tensor, torch.Tensor]:
+    def token_ids_and_weights(self, fragments: Sequence[Fragment], ranges: list = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """ranges (optional list): receives per fragment the [start, end) token positions it occupies in the 77-token
+        sequence (after the cut to 75 content tokens; BOS is position 0)."""
         tok = self.tokenizer
         ids: List[int] = []
         wts: List[float] = []
+        room = self.max_length - 2
         for text, w in fragments:
             f = self._fragment_ids(text)
+            if ranges is not None:
+                ranges.append((1 + min(len(ids), room), 1 + min(len(ids) + len(f), room)))
             ids += f
             wts += [w] * len(f)
-        room = self.max_length - 2
         ids, wts = ids[:room], wts[:room]
         pad = tok.pad_token_id if getattr(tok, "pad_token_id", None) is not None else tok.eos_token_id
         npad = room - len(ids)
@@ -145,14 +154,22 @@ class Compel:
         return torch.tensor([ids], dtype=torch.long), torch.tensor([wts], dtype=torch.float32)
 
     # -- embeddings -----------------------------------------------------------------------------------------------
-    def _encode(self, ids: torch.Tensor) -> torch.Tensor:
+    def _encode(self, ids: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
         if self.device is not None:
             ids = ids.to(self.device)
-        return self.text_encoder(ids)[0].float()
+            mask = None if mask is None else mask.to(self.device)
+        if mask is None:
+            return self.text_encoder(ids)[0].float()
+        return self.text_encoder(ids, attention_mask=mask)[0].float()
 
-    def _weighted(self, fragments: Sequence[Fragment]) -> torch.Tensor:
+    def _weighted(self, fragments: Sequence[Fragment], hide: Tuple[int, int] = None) -> torch.Tensor:
+        """z0 + (z - z0) * w per token.  hide = (start, end): those token positions are invisible as attention keys."""
         ids, w = self.token_ids_and_weights(fragments)
-        z = self._encode(ids)
+        mask = None
+        if hide is not None and hide[1] > hide[0]:
+            mask = torch.ones_like(ids)
+            mask[0, hide[0]:hide[1]] = 0
+        z = self._encode(ids, mask)
         if bool((w == 1.0).all()):
             return z
         z0 = self._encode(self.token_ids_and_weights([])[0])
@@ -164,9 +181,14 @@ class Compel:
         fragments = parse_prompt(text)
         embeddings = [self._weighted(fragments)]
         lerp = [1.0]
+        ranges: list = []
+        self.token_ids_and_weights(fragments, ranges)
         for i, (_, w) in enumerate(fragments):
             if w < 1.0:
-                embeddings.append(self._weighted(list(fragments[:i]) + list(fragments[i + 1:])))
+                if self.downweight_mode == "mask":  # Compel 2.0.2's default: same tokens, the fragment hidden in the attention
+                    embeddings.append(self._weighted(fragments, hide=ranges[i]))
+                else:
+                    embeddings.append(self._weighted(list(fragments[:i]) + list(fragments[i + 1:])))
                 lerp.append(math.tan((1.0 - max(1e-5, w)) * math.pi / 2))
         if len(embeddings) == 1:
             return embeddings[0]

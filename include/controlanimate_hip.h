@@ -280,6 +280,14 @@ typedef struct ca_attn_args {
   int32_t causal;       /* 1: key j visible to query i only if j <= i (nq == nk).  CLIP text encoder
                            (transformers CLIPTextModel's causal mask; called through Compel at
                            modules/controlanimate_pipeline.py:133-135) */
+  /* ABI v7: optional key mask, one byte per (batch z, key j) at key_mask[z * key_mask_stride + j]; 0 = the key is
+   * invisible to every query of that batch element (its score is -inf before the softmax), combined with `causal`.
+   * transformers' CLIPTextModel `attention_mask` ([B, L] -> additive [B,1,1,L]): what Compel 2.0.2's default
+   * DownweightMode.MASK passes for a down-weighted fragment such as `(muscle body)0.2`
+   * (modules/controlanimate_pipeline.py:133-135, configs/prompts/SampleConfig.yaml:16).  NULL = no mask.  A query whose
+   * keys are ALL masked gets zeros. */
+  const uint8_t* key_mask;
+  int64_t key_mask_stride;
 } ca_attn_args;
 int ca_attention(const ca_attn_args* args, void* stream);
 

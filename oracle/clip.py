@@ -64,10 +64,13 @@ def _lin(sd, p, x):
     return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
 
 
-def _encoder(sd, prefix, x, layers, heads, act, eps, causal, collect):
+def _encoder(sd, prefix, x, layers, heads, act, eps, causal, collect, attention_mask=None):
     b, n, c = x.shape
     d = c // heads
     mask = torch.full((n, n), float("-inf")).triu(1) if causal else None
+    if attention_mask is not None:  # [B, L], 1 = attend: additive [B,1,1,L] on the KEYS (transformers CLIPTextModel)
+        km = torch.zeros(b, 1, 1, n).masked_fill(~attention_mask.bool()[:, None, None, :], float("-inf"))
+        mask = km if mask is None else mask + km
     for i in range(layers):
         p = f"{prefix}.layers.{i}"
         h = _ln(sd, p + ".layer_norm1", x, eps)
@@ -83,12 +86,13 @@ def _encoder(sd, prefix, x, layers, heads, act, eps, causal, collect):
     return x
 
 
-def clip_text_forward(sd: Dict[str, torch.Tensor], cfg: CLIPTextConfig, input_ids: torch.Tensor):
+def clip_text_forward(sd: Dict[str, torch.Tensor], cfg: CLIPTextConfig, input_ids: torch.Tensor, attention_mask=None):
     """-> (last_hidden_state [B,L,C], pooler_output [B,C], hidden_states tuple of L+1 tensors)."""
     b, n = input_ids.shape
     x = sd["text_model.embeddings.token_embedding.weight"][input_ids] + sd["text_model.embeddings.position_embedding.weight"][:n]
     hs = [x]
-    x = _encoder(sd, "text_model.encoder", x, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.hidden_act, cfg.layer_norm_eps, True, hs)
+    x = _encoder(sd, "text_model.encoder", x, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.hidden_act, cfg.layer_norm_eps, True, hs,
+                 attention_mask=attention_mask)
     last = _ln(sd, "text_model.final_layer_norm", x, cfg.layer_norm_eps)
     if cfg.eos_token_id == 2:
         pos = input_ids.argmax(-1)

@@ -22,11 +22,20 @@ def main():
     ids[0, 9], ids[1, 15] = 99, 99  # the highest id plays EOS (legacy eos_token_id == 2 -> argmax)
     with torch.no_grad():
         out = tm(input_ids=ids, output_hidden_states=True)
+        # the same prompts with some tokens hidden as attention KEYS (transformers' attention_mask, added to the causal mask):
+        # what Compel's default DownweightMode.MASK passes for a down-weighted fragment
+        amask = torch.ones(2, 16, dtype=torch.long)
+        amask[0, 3:6] = 0
+        amask[1, 7] = 0
+        amask[1, 11:13] = 0
+        out_m = tm(input_ids=ids, attention_mask=amask, output_hidden_states=True)
     # checkpoint naming (transformers 4.x, what the SD1.5 text_encoder files use): `text_model.` prefix;
     # transformers 5.x dropped the wrapper level in state_dict()
     sd = {(k if k.startswith("text_model.") else "text_model." + k): v.numpy() for k, v in tm.state_dict().items() if "position_ids" not in k}
     np.savez_compressed(os.path.join(HERE, "clip_text_tiny.npz"), input_ids=ids.numpy(), last_hidden_state=out.last_hidden_state.numpy(),
                         pooler_output=out.pooler_output.numpy(), hidden_1=out.hidden_states[1].numpy(),
+                        attention_mask=amask.numpy(), masked_last_hidden_state=out_m.last_hidden_state.numpy(),
+                        masked_pooler_output=out_m.pooler_output.numpy(),
                         **{"w:" + k: v for k, v in sd.items()})
 
     torch.manual_seed(1)

@@ -24,6 +24,19 @@ def test_text_oracle_matches_transformers():
     assert torch.allclose(hs[1], torch.from_numpy(z["hidden_1"]), atol=2e-5) and len(hs) == 3
 
 
+def test_text_oracle_with_attention_mask_matches_transformers():
+    """transformers' CLIPTextModel with an attention_mask (tokens hidden as keys, on top of the causal mask): the call
+    Compel's default down-weighting makes (modules/controlanimate_pipeline.py:133-135)."""
+    from oracle.clip import CLIPTextConfig, clip_text_forward
+    z, sd = _load("clip_text_tiny.npz")
+    am = torch.from_numpy(z["attention_mask"])
+    assert int((am == 0).sum()) == 6
+    last, pooled, _ = clip_text_forward(sd, CLIPTextConfig(**TEXT_TINY), torch.from_numpy(z["input_ids"]), attention_mask=am)
+    assert torch.allclose(last, torch.from_numpy(z["masked_last_hidden_state"]), atol=2e-5)
+    assert torch.allclose(pooled, torch.from_numpy(z["masked_pooler_output"]), atol=2e-5)
+    assert not torch.allclose(last, torch.from_numpy(z["last_hidden_state"]), atol=1e-3)  # the mask matters
+
+
 def test_vision_oracle_matches_transformers():
     from oracle.clip import CLIPVisionConfig, clip_vision_forward
     z, sd = _load("clip_vision_tiny.npz")

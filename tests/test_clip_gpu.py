@@ -31,6 +31,26 @@ def test_text_tiny_fixture_from_transformers():
     assert rel(out.hidden_states[1], torch.from_numpy(z["hidden_1"])) < 5e-3 and len(out.hidden_states) == 3
 
 
+def test_text_tiny_fixture_with_attention_mask_from_transformers():
+    """ca_attention's key mask (ABI v7) under the causal mask == transformers' CLIPTextModel(attention_mask=...)."""
+    from controlanimate_amd.clip import CLIPTextModel
+    from tests.test_clip_cpu import TEXT_TINY
+    z = np.load(os.path.join(GOLD, "clip_text_tiny.npz"))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    m = CLIPTextModel.from_config(TEXT_TINY)
+    m.load_state_dict(sd)
+    m.to(DEV).prepare(DEV)
+    ids, am = torch.from_numpy(z["input_ids"]).to(DEV), torch.from_numpy(z["attention_mask"]).to(DEV)
+    out = m(ids, attention_mask=am)
+    assert rel(out[0], torch.from_numpy(z["masked_last_hidden_state"])) < 5e-3
+    assert rel(out.pooler_output, torch.from_numpy(z["masked_pooler_output"])) < 5e-3
+    plain = m(ids)
+    assert rel(plain[0], torch.from_numpy(z["last_hidden_state"])) < 5e-3
+    assert rel(out[0], plain[0]) > 1e-2  # the mask matters
+    # an all-ones mask is the plain call, bit for bit
+    assert torch.equal(m(ids, attention_mask=torch.ones_like(am))[0], plain[0])
+
+
 def test_vision_tiny_fixture_from_transformers():
     from controlanimate_amd.clip import CLIPVisionModelWithProjection
     from tests.test_clip_cpu import VIS_TINY

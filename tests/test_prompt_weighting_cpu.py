@@ -48,10 +48,14 @@ class Tok:
         return SimpleNamespace(input_ids=[self.bos_token_id] + ids[: self.model_max_length - 2] + [self.eos_token_id])
 
 
-def encoder(ids):
-    """A causal toy encoder: position p sees the ids up to p (so removing a fragment changes everything after it)."""
+def encoder(ids, attention_mask=None):
+    """A causal toy encoder: position p sees the ids up to p (so removing a fragment changes everything after it);
+    attention_mask [B, L] hides positions as KEYS, as transformers' CLIPTextModel does."""
     e = torch.sin(ids.float()[..., None] * torch.arange(1, 9).float() * 0.37)
-    return (torch.cumsum(e, 1) / torch.arange(1, ids.shape[1] + 1).float()[None, :, None],)
+    if attention_mask is None:
+        return (torch.cumsum(e, 1) / torch.arange(1, ids.shape[1] + 1).float()[None, :, None],)
+    m = attention_mask.float()[..., None]
+    return (torch.cumsum(e * m, 1) / torch.cumsum(m, 1).clamp_min(1.0),)
 
 
 def test_weighting_arithmetic():
@@ -65,15 +69,29 @@ def test_weighting_arithmetic():
     up = c("a (red)++ cat")
     wt = torch.ones(1, 12, 1); wt[0, 2] = 1.21                             # BOS, a, red, cat, EOS, pad...
     assert torch.allclose(up, z0 + (z - z0) * wt, atol=1e-6)
-    # w < 1: blend with the prompt WITHOUT the fragment, tan((1 - w) pi / 2) : 1
-    down = c("a (red)0.5 cat")
+    # w < 1, DownweightMode.REMOVE: blend with the prompt WITHOUT the fragment, tan((1 - w) pi / 2) : 1
+    cr = Compel(tokenizer=tok, text_encoder=encoder, downweight_mode="remove")
+    down = cr("a (red)0.5 cat")
     wt[0, 2] = 0.5
     base = z0 + (z - z0) * wt
     without = encoder(c.token_ids_and_weights([("a", 1.0), ("cat", 1.0)])[0])[0]
     t = math.tan(0.5 * math.pi / 2)
     assert torch.allclose(down, (base + t * without) / (1 + t), atol=1e-6)
     # w -> 0: the fragment is as good as removed
-    assert torch.allclose(c("a (red)0.0001 cat"), without, atol=1e-3)
+    assert torch.allclose(cr("a (red)0.0001 cat"), without, atol=1e-3)
+    # w < 1, DownweightMode.MASK (Compel 2.0.2's default, and this class's): the SAME tokens with the fragment's positions
+    # hidden in the attention mask, weighted per token like the base embedding
+    assert c.downweight_mode == "mask"
+    mask = torch.ones(1, 12, dtype=torch.long)
+    mask[0, 2] = 0                                                         # "red"
+    zm = encoder(plain_ids, attention_mask=mask)[0]
+    masked = z0 + (zm - z0) * wt
+    assert torch.allclose(c("a (red)0.5 cat"), (base + t * masked) / (1 + t), atol=1e-6)
+    assert not torch.allclose(c("a (red)0.5 cat"), down, atol=1e-4)        # the two modes differ
+    # a two-token fragment in the middle of the reference's sample prompt: positions 3..4 are hidden
+    ranges = []
+    c.token_ids_and_weights(parse_prompt("room (muscle body)0.2, fully dressed"), ranges)
+    assert ranges[1] == (2, 4)
     # truncation to max_length - 2 tokens, weights cut with them
     ids, wts = c.token_ids_and_weights([("w1 w2 w3 w4 w5 w6", 1.0), ("w7 w8 w9 w10 w11 w12", 1.5)])
     assert ids.shape == (1, 12) and ids[0, -1] == 2 and wts[0].tolist() == [1.0] * 7 + [1.5] * 4 + [1.0]
