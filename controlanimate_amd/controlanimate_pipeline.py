@@ -84,7 +84,14 @@ def _has_safetensors(base, sub) -> bool:
 
 
 class ControlAnimatePipeline:
-    def __init__(self, config, components: Optional[Dict[str, Any]] = None, device=None):
+    def __init__(self, config, components: Optional[Dict[str, Any]] = None, device=None, skeleton: bool = False):
+        """skeleton=True (ranks > 0 of vid2vid.run_video_sharded): the same object, built from the config files WITHOUT reading
+        any weight file -- the packed weight arenas are then received from rank 0 (`weight_buffers`)."""
+        if skeleton and components is None:
+            from .local_models import skeleton_weights
+            with skeleton_weights():
+                self.__init__(config, None, device, skeleton=False)
+            return
         self.use_lcm = bool(_get(config, "use_lcm", 0))
         # the reference hard-wires "cuda"; without a GPU the object can still be built (files read, weights fused, prompts
         # converted) but animate() fails loudly: the execution path has no CPU fallback
@@ -113,7 +120,8 @@ class ControlAnimatePipeline:
             self.pipeline.ip_adapter = ip
             if self.multicontrolnetresiduals_pipeline is not None:
                 ip.set_ip_adapter_4controlanimate(self.multicontrolnetresiduals_pipeline)
-        if built_here:  # reference :87-106: motion module, DreamBooth checkpoint, LoRAs, motion LoRAs
+        from .local_models import is_skeleton
+        if built_here and not is_skeleton():  # reference :87-106: motion module, DreamBooth checkpoint, LoRAs, motion LoRAs
             from .weight_ingest import load_weights
             lora_paths = _get(config, "lora_model_paths", "") or ""
             kw = {} if self.use_lcm else dict(dreambooth_model_path=_get(config, "dreambooth_path", "") or "",
@@ -143,6 +151,26 @@ class ControlAnimatePipeline:
         for m in models:
             m.prepare(self.device, self._dtype)
         self._prepared = True
+
+    def weight_buffers(self) -> list:
+        """Every device tensor the execution path reads that came out of a checkpoint: the packed weight arena of each
+        model (ONE contiguous buffer each) and the few tables that are used unpacked (CLIP's token / position embeddings).
+        What rank 0 broadcasts to the other ranks of a window-sharded run (window_shard.broadcast_weights), in a fixed order."""
+        if not self._prepared:
+            self._prepare_models()
+        models = [self.pipeline.unet] + (list(self.multicontrolnetresiduals_pipeline.controlnets) if self.multicontrolnetresiduals_pipeline else [])
+        models += [m for m in (self.pipeline.vae, self.pipeline.text_encoder) if m is not None and getattr(m, "arena", None) is not None]
+        ip = getattr(self.pipeline, "ip_adapter", None)
+        if ip is not None and getattr(getattr(ip, "image_encoder", None), "arena", None) is not None:
+            models.append(ip.image_encoder)
+        bufs = [m.arena.buffer for m in models]
+        te = self.pipeline.text_encoder
+        emb = getattr(getattr(te, "text_model", None), "embeddings", None)
+        if emb is not None:
+            bufs += [emb.token_embedding.weight.data, emb.position_embedding.weight.data]
+        if ip is not None:
+            bufs += [p_.data for p_ in getattr(ip, "image_proj_model", torch.nn.Module()).parameters()]
+        return bufs
 
     def _encode_plain(self, prompt: str) -> torch.Tensor:
         tok = self.pipeline.tokenizer

@@ -71,7 +71,33 @@ def resolve_model_dir(name: str, subfolder: Optional[str] = None, extra_roots: S
                             " is not on disk and there is no network to download it; looked in: " + ", ".join(tried))
 
 
+_SKELETON = False
+
+
+class skeleton_weights:
+    """`with skeleton_weights(): ...` -- the model loaders below build their modules from the config files WITHOUT reading the
+    weight files (parameters keep their default initialisation).  The ranks > 0 of a window-sharded run build their models
+    this way, pack them (`prepare()`: the arenas get their final layout) and then RECEIVE the arena contents from rank 0
+    over RCCL (vid2vid.run_video_sharded, window_shard.broadcast_weights): one process reads the checkpoints, not eight."""
+
+    def __enter__(self):
+        global _SKELETON
+        self._old, _SKELETON = _SKELETON, True
+        return self
+
+    def __exit__(self, *exc):
+        global _SKELETON
+        _SKELETON = self._old
+        return False
+
+
+def is_skeleton() -> bool:
+    return _SKELETON
+
+
 def load_dir_state_dict(model_dir: str) -> Dict[str, torch.Tensor]:
+    if _SKELETON:
+        return {}
     for n in WEIGHT_NAMES:
         f = os.path.join(model_dir, n)
         if os.path.isfile(f):
@@ -106,6 +132,8 @@ def load_vae(pretrained_model_path: str, vae_path: str = ""):
     from .weight_ingest import convert_ldm_vae_checkpoint
     if vae_path:
         vae = AutoencoderKL.from_config()
+        if _SKELETON:
+            return vae
         sd = read_checkpoint(vae_path)
         if any(k.startswith("first_stage_model.") for k in sd) or any(k.startswith("encoder.down.") for k in sd):
             if not any(k.startswith("first_stage_model.") for k in sd):
@@ -117,7 +145,7 @@ def load_vae(pretrained_model_path: str, vae_path: str = ""):
     cfg = load_dir_config(d)
     from .vae import VAE_CONFIG
     vae = AutoencoderKL.from_config({k: v for k, v in cfg.items() if k in VAE_CONFIG})
-    vae.load_state_dict(load_dir_state_dict(d))
+    vae.load_state_dict(load_dir_state_dict(d), strict=not _SKELETON)
     return vae
 
 
@@ -127,7 +155,7 @@ def load_text_encoder(pretrained_model_path: str):
     d = resolve_model_dir(pretrained_model_path, "text_encoder")
     cfg = load_dir_config(d)
     te = CLIPTextModel.from_config({k: v for k, v in cfg.items() if k in TEXT_CONFIG})
-    te.load_state_dict(load_dir_state_dict(d))
+    te.load_state_dict(load_dir_state_dict(d), strict=not _SKELETON)
     return te
 
 

@@ -474,6 +474,9 @@ class UNet3DConditionModel(HipModelMixin, nn.Module):
         config["down_block_types"] = ["CrossAttnDownBlock3D"] * 3 + ["DownBlock3D"]
         config["up_block_types"] = ["UpBlock3D"] + ["CrossAttnUpBlock3D"] * 3
         model = cls.from_config(config, **(unet_additional_kwargs or {}))
+        from .local_models import is_skeleton
+        if is_skeleton():  # a rank > 0 of a window-sharded run: the packed weights arrive from rank 0 (local_models.skeleton_weights)
+            return model
         name = "diffusion_pytorch_model.safetensors" if use_safetensors else "diffusion_pytorch_model.bin"
         model_file = os.path.join(pretrained_model_path, name)
         if not os.path.isfile(model_file):

@@ -303,3 +303,68 @@ def blend_windows(windows: Sequence[Sequence], overlap_length: int,
         is_last = k == len(windows) - 1
         out += frames if is_last else frames[:len(frames) - len(overlap_frames)]
     return out
+
+
+def run_video_sharded(config, frames: Sequence, components: Optional[dict] = None,
+                      match_colors_fn: Optional[Callable[[Sequence, object], List]] = match_colors, device=None):
+    """The window loop of scripts/vid2vid.py:168-268 over the GPUs of one node: one process per GPU (torchrun or any launcher
+    that sets RANK / LOCAL_RANK / WORLD_SIZE), every rank calls this with the same `config` and the same input `frames`.
+
+      1. `init_distributed` (RCCL over xGMI; gloo when CA_DIST_BACKEND=gloo);
+      2. rank 0 builds ControlAnimatePipeline(config) from the checkpoints; every other rank builds the same object from
+         the config files alone (`skeleton=True`: no weight file is read), packs it -- its arenas then have the final layout
+         -- and RECEIVES the arena contents: `broadcast_weights(pipe.weight_buffers())`, a handful of multi-GB transfers;
+      3. the sliding-window plan (`window_plan`); rank r runs `animate` on windows r, r + W, ... -- NO collective in the loop;
+      4. the decoded frames of every window are gathered on rank 0 (uint8, ~12 MB per 16-frame 512x512 window), which does the
+         colour matching against the previous window and the cross-fade of the overlap IN WINDOW ORDER (`blend_windows`),
+         exactly as the sequential loop (`run_windows`) does, and returns the final frame list; the other ranks return None.
+
+    Windows are independent problems -- and the result equal to the sequential loop's, frame for frame (tests/
+    test_facade_gpu.py::test_sharded_video_equals_sequential) -- only when nothing flows from window k to window k + 1 before
+    the blend: `overlap_strength >= 1` (no latent initialisation from the previous output, :566-604), `loop_back_frames` off
+    (:197-199), no IP-Adapter conditioning on the previous window's frame (:698-710).  Any other configuration is a chain by
+    construction and is refused here; run it with `run_windows` on one GPU.  (A sampler that draws its step noise
+    from the SAME generator as the VAE's latent sampling -- diffusers' ancestral / LCM samplers -- sees a different generator
+    state in the two modes, because the sequential loop also encodes the previous window's frames: statistically the same
+    video, not the same bits.  Deterministic samplers and the native LCM sampler, whose noise comes from the global RNG that
+    `animate` re-seeds per window, agree bit for bit.)"""
+    from . import window_shard as WS
+    from .controlanimate_pipeline import ControlAnimatePipeline, _get
+    frame_count, overlap = int(_get(config, "frame_count", 16)), int(_get(config, "overlap_length", 0))
+    if overlap > 0 and float(_get(config, "overlap_strength", 1.0)) < 1.0:
+        raise ValueError("window sharding needs overlap_strength >= 1: with less, a window starts from the previous window's output "
+                         "latents and the windows form a chain (use run_windows on one GPU)")
+    if bool(_get(config, "loop_back_frames", False)) and overlap > 0:
+        raise ValueError("window sharding needs loop_back_frames off: looped-back frames are the previous window's OUTPUT")
+    if bool(_get(config, "use_ipadapter", 0)):
+        raise ValueError("window sharding is not available with the IP-Adapter: it conditions a window on the previous window's frame")
+    rank, world, local_rank = WS.init_distributed()
+    if device is None:
+        device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    if torch.device(device).type == "cuda":
+        torch.cuda.set_device(device)
+    pipe = ControlAnimatePipeline(config, components=components, device=device, skeleton=(rank != 0 and components is None))
+    moved = WS.broadcast_weights(pipe.weight_buffers())
+    frames = list(frames)
+    plan = WS.window_plan(len(frames), frame_count, overlap)
+
+    def cfg_of(k: int) -> dict:
+        s, e = plan[k]
+        c = dict(config) if isinstance(config, dict) else {kk: getattr(config, kk) for kk in dir(config) if not kk.startswith("_") and not callable(getattr(config, kk))}
+        later = k > 0 and overlap > 0
+        c.update(frame_count=e - s, L=e - s, epoch=k, overlap=later, overlaps=overlap if later else 0,
+                 strength=float(_get(config, "overlap_strength", 1.0)) if later else float(_get(config, "strength", 1.0)))
+        return c
+
+    def run_window(k: int) -> torch.Tensor:
+        s, e = plan[k]
+        out = pipe.animate(frames[s:e], None, cfg_of(k))
+        return torch.from_numpy(np.stack([_to_np(f) for f in out]))  # [n, H, W, 3] uint8
+
+    windows = WS.run_sharded(len(plan), run_window, rank, world)
+    run_video_sharded.last_broadcast_bytes = moved
+    if rank != 0 or windows is None:
+        return None
+    # (PIL frames, as the sequential loop handles them: Image.blend's arithmetic, byte for byte)
+    as_frame = (lambda a: Image.fromarray(a)) if Image is not None else (lambda a: a)
+    return blend_windows([[as_frame(w[i].numpy()) for i in range(w.shape[0])] for w in windows], overlap, match_colors_fn)

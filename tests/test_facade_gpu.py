@@ -62,3 +62,65 @@ def test_animate_end_to_end_all_hip():
     cfg2 = dict(cfg, seed=8)
     a3 = np.stack([np.asarray(f) for f in pipe.animate(frames_in, None, cfg2)])
     assert not np.array_equal(a1, a3)
+
+
+def _sharded_worker(rank, world, port, cfg, seed_frames, out_path):
+    """One rank of run_video_sharded; both ranks share GPU 0 (gloo rendezvous: the 1-GPU rehearsal of the node-level flow)."""
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      CA_DIST_BACKEND="gloo")
+    import numpy as np
+    import torch
+    from PIL import Image
+    from controlanimate_amd import vid2vid
+    rng = np.random.default_rng(seed_frames)
+    frames = [Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)) for _ in range(20)]
+    comps = _components()
+    if rank != 0:  # what a skeleton rank has before the broadcast: the right shapes, the wrong numbers
+        for m in (comps["unet"], comps["controlnets"][0], comps["vae"], comps["text_encoder"]):
+            for p in m.parameters():
+                p.data.normal_(std=0.02)
+    out = vid2vid.run_video_sharded(cfg, frames, components=comps, device="cuda:0")
+    if rank == 0:
+        np.save(out_path, np.stack([np.asarray(f) for f in out]))
+        assert vid2vid.run_video_sharded.last_broadcast_bytes > 10_000_000
+    else:
+        assert out is None
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_video_equals_sequential(tmp_path):
+    """scripts/vid2vid.py's window loop sharded over two ranks (windows r, r + 2, ...; weights broadcast from rank 0, whose
+    arenas OVERWRITE rank 1's differently-initialised ones; colour match + cross-fade on rank 0) == the sequential loop
+    (`run_windows`) on one process, byte for byte -- with overlap_strength >= 1, no loop-back, a deterministic sampler."""
+    import socket
+    import torch.multiprocessing as mp
+    from controlanimate_amd import vid2vid
+    from controlanimate_amd.controlanimate_pipeline import ControlAnimatePipeline
+    cfg = dict(use_lcm=0, controlnets=["lllyasviel/control_v11p_sd15_canny"], cond_scale=[0.8], scheduler="DDIMScheduler",
+               prompt="a red fox running", n_prompt="blurry", seed=7, width=64, height=64, steps=3, strength=1.0, overlap_strength=1.0,
+               guidance_scale=1.3, frame_count=8, overlap_length=4, overlaps=0, epoch=0, guess_mode=0, use_img2img=True, loop_back_frames=False)
+    # ---- sequential reference, this process
+    rng = np.random.default_rng(123)
+    frames = [Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)) for _ in range(20)]
+    pipe = ControlAnimatePipeline(cfg, _components(), device=DEV)
+    wc = vid2vid.WindowConfig(frame_count=8, overlap_length=4, strength=1.0, overlap_strength=1.0, loop_back_frames=False)
+
+    def animate(batch, last, c):
+        return pipe.animate(batch, last, dict(cfg, frame_count=c.frame_count, strength=c.strength, overlaps=c.overlaps, epoch=c.epoch))
+
+    seq = [f for win in vid2vid.run_windows(frames, animate, wc) for f in win]
+    seq = np.stack([np.asarray(f) for f in seq])
+    assert seq.shape == (20, 64, 64, 3)
+    del pipe
+    torch.cuda.empty_cache()
+    # ---- two ranks on this GPU
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "sharded.npy")
+    mp.spawn(_sharded_worker, args=(2, port, cfg, 123, out_path), nprocs=2, join=True)
+    sharded = np.load(out_path)
+    assert sharded.shape == seq.shape
+    assert np.array_equal(sharded, seq), f"{int((sharded != seq).sum())} bytes differ"
