@@ -38,15 +38,7 @@
 // Epilogue arithmetic and rounding order are those of gemm_epilogue (ca_gemm_core.h): round((acc [LN fold] + bias +
 // rowbias) * alpha), then + residual, * post, activation, GEGLU, round.
 
-struct CaSeqTable {
-  unsigned v[1024];
-};
-constexpr CaSeqTable ca_make_seq_table() {
-  CaSeqTable t{};
-  for (int i = 0; i < 1024; ++i) t.v[i] = (unsigned)i;
-  return t;
-}
-__device__ const CaSeqTable ca_seq_table = ca_make_seq_table();
+#include "ca_gemm_seq.h"
 
 // exact counted wait for 0 <= n <= 23 (larger: 23 = a safe over-wait); one asm statement, a balanced tree of scalar compares
 __device__ __forceinline__ void ca_ps_vm_wait(int n) {

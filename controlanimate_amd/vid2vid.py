@@ -328,6 +328,7 @@ def run_video_sharded(config, frames: Sequence, components: Optional[dict] = Non
     state in the two modes, because the sequential loop also encodes the previous window's frames: statistically the same
     video, not the same bits.  Deterministic samplers and the native LCM sampler, whose noise comes from the global RNG that
     `animate` re-seeds per window, agree bit for bit.)"""
+    import torch
     from . import window_shard as WS
     from .controlanimate_pipeline import ControlAnimatePipeline, _get
     frame_count, overlap = int(_get(config, "frame_count", 16)), int(_get(config, "overlap_length", 0))
