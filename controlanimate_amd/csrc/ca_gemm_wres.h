@@ -325,7 +325,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
               }
             }
           }
-          __builtin_amdgcn_raw_buffer_store_b128(w, rs_c, off[i], q * 64, 0);
+          // (the column offset goes into the instruction's immediate field, NOT the SGPR soffset operand: on gfx950 a
+          //  buffer_store_dwordx4 with a register soffset followed directly by a VALU write of its data registers stored
+          //  the NEW values for lanes 12-15 of each 16 -- hipcc 7.2 only keeps the one wait state for immediate offsets;
+          //  DESIGN.md section 3, "16-byte store hazard")
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs_c, off[i] + (unsigned)(q * 64), 0, 0);
         }
       }
       continue;
