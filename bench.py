@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--shapes", action="store_true", help="also print the per-shape GEMM/conv table (stderr)")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing (reported beside the metric)")
     ap.add_argument("--no-overlap", action="store_true", help="run the ControlNet stack on the main stream (no 2nd-stream overlap)")
+    ap.add_argument("--no-fuse-adds", action="store_true", help="13 separate ControlNet residual adds instead of the zero convolutions' epilogues (A/B)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly.  Default: the ControlNet + UNet part of a step is captured once as a "
                          "hipGraph (both streams) and replayed -- same kernels, bit-identical results "
@@ -549,6 +550,7 @@ def main():
     pipe = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched).to(device)
     pipe.use_hip_graph = not args.no_graph
     pipe.overlap_controlnet = not args.no_overlap
+    pipe.fuse_controlnet_adds = not args.no_fuse_adds
     lat0 = latents * float(getattr(sched, "init_noise_sigma", 1.0))
     gen = torch.Generator(device="cpu").manual_seed(4321)
     state = {"latents": lat0}

@@ -50,6 +50,7 @@ class ControlAnimationPipeline:
         # instead of ~50 ms of host time per step: with 8 ranks on one host the loop stays GPU-bound.  A failed capture is
         # logged and the window runs eagerly (`graph_fallback_reason`).
         self.use_hip_graph = True
+        self.fuse_controlnet_adds = True  # (False: separate ca_add_bcast passes, as round 2 -- A/B runs and the tests that compare the two)
         self._graph_state = None
         self._noise_state = None
         if scheduler is None:  # native LCM (reference :95-101)
@@ -320,7 +321,7 @@ class ControlAnimationPipeline:
             nets = list(getattr(cn, "controlnets", [])) if cn is not None else []
             sig = (id(unet), id(unet.arena), tuple(id(n.arena) for n in nets), id(cn), rep, f, hh, ww, cpad, str(unet.act_dtype),
                    tuple(unet_prompt.shape), tuple(cn_prompt.shape) if cn is not None else None, bool(cn_single), bool(guess_mode),
-                   bool(use_lcm), w_embedding is not None, bool(getattr(self, "overlap_controlnet", True)),
+                   bool(use_lcm), w_embedding is not None, bool(getattr(self, "overlap_controlnet", True)), bool(getattr(self, "fuse_controlnet_adds", True)),
                    tuple(tuple(pi.shape) for pi in cn.prep_images) if cn is not None else None,
                    tuple(id(pi) for pi in cn.prep_images) if cn is not None else None,
                    # host-side scalars that are baked into captured launches
@@ -351,7 +352,9 @@ class ControlAnimationPipeline:
                 x_cn = x if (rep == 1 or not cn_single) else x[:f]
                 twice = rep == 2 and not cn_single  # the ControlNet sees both (identical) CFG halves of the latents
                 if getattr(self, "overlap_controlnet", True):
-                    down = cn.residuals_nhwc_async(x_cn, tt, cn_prompt, guess_mode, cfg_identical_halves=twice)  # joined inside the UNet
+                    # joined inside the UNet; the 13 residual adds fused into the zero convolutions when the batches agree
+                    down = cn.residuals_nhwc_async(x_cn, tt, cn_prompt, guess_mode, cfg_identical_halves=twice,
+                                                   fuse_images=x.shape[0] if getattr(self, "fuse_controlnet_adds", True) else 0)
                 else:
                     down, mid = cn.residuals_nhwc(x_cn, tt, cn_prompt, guess_mode, cfg_identical_halves=twice)
             # x = latents_to_nhwc(latents, rep): for rep == 2 the two CFG halves are the same tensor (reference :797)

@@ -161,11 +161,9 @@ class ControlNetModel(HipModelMixin, nn.Module):
         return [float(conditioning_scale)] * n
 
     @torch.no_grad()
-    def forward_nhwc(self, x: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
-                     conditioning_scale: float = 1.0, guess_mode: bool = False,
-                     accumulate: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None, cfg_identical_halves: bool = False):
-        """x: [B,h,w,cin_pad] activation dtype. Returns (12 NHWC residuals, mid), already scaled and --
-        if `accumulate` holds the running sums of previous nets -- added to them."""
+    def forward_body(self, x: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
+                     conditioning_scale: float = 1.0, guess_mode: bool = False, cfg_identical_halves: bool = False):
+        """Everything up to the zero convolutions: -> (the 12 block outputs, the mid-block output, the 13 residual scales)."""
         device = x.device
         self._ensure_ready(device)
         images = x.shape[0]
@@ -196,7 +194,14 @@ class ControlNetModel(HipModelMixin, nn.Module):
             x, o = blk(x, ctx)
             outs += o
         x = self.mid_block(x, ctx)
-        scales = self.residual_scales(conditioning_scale, guess_mode)
+        return outs, x, self.residual_scales(conditioning_scale, guess_mode)
+
+    @torch.no_grad()
+    def apply_zero_convs(self, outs, x, scales, accumulate: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None):
+        """The 13 zero convolutions: residual_i = scale_i * (zc_i(out_i)) [+ accumulate_i].  `accumulate` holds the running sums
+        of the previous nets -- or, for the first net of a fused step, the UNet's own skip tensors and mid-block output
+        (reference unet.py:567-576, 584-585: `sample + residual`): the add then happens in this GEMM's epilogue and the
+        result IS the tensor the UNet's up blocks consume."""
         down = []
         for i, (zc, o) in enumerate(zip(self.controlnet_down_blocks, outs)):
             B_, h, w, c = o.shape
@@ -206,6 +211,16 @@ class ControlNetModel(HipModelMixin, nn.Module):
         prev = None if accumulate is None else accumulate[1].view(B_ * h * w, c)
         mid = self.controlnet_mid_block.run(x.view(B_ * h * w, c), alpha=scales[-1], residual=prev).view(B_, h, w, c)
         return down, mid
+
+    @torch.no_grad()
+    def forward_nhwc(self, x: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
+                     conditioning_scale: float = 1.0, guess_mode: bool = False,
+                     accumulate: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None, cfg_identical_halves: bool = False):
+        """x: [B,h,w,cin_pad] activation dtype. Returns (12 NHWC residuals, mid), already scaled and --
+        if `accumulate` holds the running sums of previous nets -- added to them."""
+        outs, xm, scales = self.forward_body(x, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, guess_mode,
+                                             cfg_identical_halves)
+        return self.apply_zero_convs(outs, xm, scales, accumulate)
 
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
                 conditioning_scale: float = 1.0, class_labels=None, timestep_cond=None, attention_mask=None,
@@ -239,6 +254,20 @@ class MultiControlNetModel(nn.Module):
         for n in self.nets:
             n.prepare(device, dtype)
         return self
+
+    def forward_bodies(self, x, timestep, encoder_hidden_states, controlnet_cond: Sequence[torch.Tensor],
+                       conditioning_scale: Sequence[float], guess_mode: bool = False, cfg_identical_halves: bool = False):
+        """Every net up to its zero convolutions (see ControlNetModel.forward_body): the part of the stack that does not need
+        the UNet's skip tensors."""
+        return [net.forward_body(x, timestep, encoder_hidden_states, cond, scale, guess_mode, cfg_identical_halves)
+                for net, cond, scale in zip(self.nets, controlnet_cond, conditioning_scale)]
+
+    def finish(self, bodies, base: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None):
+        """Zero convolutions of every net, summed -- on top of `base` = (the UNet's skips, its mid-block output) when given."""
+        acc = base
+        for net, (outs, xm, scales) in zip(self.nets, bodies):
+            acc = net.apply_zero_convs(outs, xm, scales, acc)
+        return acc
 
     def forward_nhwc(self, x, timestep, encoder_hidden_states, controlnet_cond: Sequence[torch.Tensor],
                      conditioning_scale: Sequence[float], guess_mode: bool = False, cfg_identical_halves: bool = False):

@@ -107,12 +107,18 @@ class MultiControlNetResidualsPipeline:
                                             cfg_identical_halves=cfg_identical_halves)
 
     def residuals_nhwc_async(self, x_nhwc: torch.Tensor, t, controlnet_prompt_embeds: torch.Tensor, guess_mode: bool,
-                             cfg_identical_halves: bool = False):
+                             cfg_identical_halves: bool = False, fuse_images: int = 0):
         """Same as residuals_nhwc, but enqueued on a second HIP stream so the ControlNet stack runs beside
         the UNet encoder (they are independent until the residual adds, unet.py:567-586): the kernels of
         one fill the CUs the other leaves idle in its launch tails and small-grid levels.  Returns
         join() -> (down, mid), which makes the CALLER's current stream wait for the residuals.
-        UNet3DConditionModel.forward_nhwc accepts the join callable in place of `down_residuals`."""
+        UNet3DConditionModel.forward_nhwc accepts the join callable in place of `down_residuals`.
+
+        fuse_images = the UNet's image count (rep * f).  When the ControlNets see the same batch, their zero convolutions are
+        deferred: join(skips, mid) -- called by the UNet with its 12 skip tensors and its mid-block output once its encoder
+        is done -- runs them on the second stream with those tensors as the epilogue's residual operand and returns
+        (skips + residuals, mid + residual): the reference's 13 `sample + residual` adds (unet.py:567-576, 584-585) happen
+        inside GEMMs that run anyway, instead of 13 extra passes over the tensors (`join.fuse`)."""
         dev = x_nhwc.device
         main = torch.cuda.current_stream(dev)
         side = getattr(self, "_side_stream", None)
@@ -121,21 +127,42 @@ class MultiControlNetResidualsPipeline:
         # (inside a hipGraph capture the fork/join below become graph edges; the allocator's cross-stream
         # bookkeeping is not needed there -- the graph's private pool outlives every replay)
         capturing = torch.cuda.is_current_stream_capturing()
+        fuse = bool(fuse_images) and int(fuse_images) == int(x_nhwc.shape[0]) and self.prep_images is not None
         side.wait_stream(main)  # x_nhwc (and on the first call the weights) were produced on `main`
         with torch.cuda.stream(side):
-            down, mid = self.residuals_nhwc(x_nhwc, t, controlnet_prompt_embeds, guess_mode, cfg_identical_halves)
-            done = side.record_event()
+            if fuse:
+                bodies = self.controlnet.forward_bodies(x_nhwc, t, controlnet_prompt_embeds, self.prep_images, self.cond_scale, guess_mode,
+                                                        cfg_identical_halves=cfg_identical_halves)
+            else:
+                down, mid = self.residuals_nhwc(x_nhwc, t, controlnet_prompt_embeds, guess_mode, cfg_identical_halves)
+                done = side.record_event()
         if not capturing:
             x_nhwc.record_stream(side)
 
-        def join():
+        def join(skips=None, mid_x=None):
             cur = torch.cuda.current_stream(dev)
-            cur.wait_event(done)
+            if not fuse:
+                cur.wait_event(done)
+                if not capturing:
+                    for r in (*down, mid):
+                        r.record_stream(cur)  # allocated on `side`, read on `cur`
+                return down, mid
+            if skips is None or mid_x is None:
+                raise RuntimeError("a fused ControlNet join needs the UNet's skip tensors and mid-block output")
+            side.wait_stream(cur)  # the UNet's encoder (skips, mid) is complete on the caller's stream
+            with torch.cuda.stream(side):
+                d2, m2 = self.controlnet.finish(bodies, (list(skips), mid_x))
+                fin = side.record_event()
             if not capturing:
-                for r in (*down, mid):
-                    r.record_stream(cur)  # allocated on `side`, read on `cur`
-            return down, mid
+                for s_ in (*skips, mid_x):
+                    s_.record_stream(side)  # allocated on `cur`, read on `side`
+            cur.wait_event(fin)
+            if not capturing:
+                for r in (*d2, m2):
+                    r.record_stream(cur)
+            return d2, m2
 
+        join.fuse = fuse
         return join
 
     @torch.no_grad()

@@ -99,6 +99,13 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
       return CA_OK;
     }
 #endif
+#ifdef CA_EXPERIMENTS
+    static const int ps_flags = CA_KNOB("CA_PS_FLAGS", 1);
+    if (!ps_flags) {
+      hipLaunchKernelGGL((k_gemm_ps<DT, MODE, false>), dim3(grid), dim3(512), 0, st, p, (int)tiles, c_bytes, res_bytes);
+      return CA_OK;
+    }
+#endif
     hipLaunchKernelGGL((k_gemm_ps<DT, MODE>), dim3(grid), dim3(512), 0, st, p, (int)tiles, c_bytes, res_bytes);
     return CA_OK;
   }

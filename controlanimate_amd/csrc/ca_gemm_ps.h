@@ -86,7 +86,12 @@ __device__ __forceinline__ int ca_ps_col(int j, int i, bool geglu) {
   return 32 * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3);
 }
 
-template <int DT, int MODE>
+// FLAGS = false (experiment, CA_PS_FLAGS=0): the same kernel with COUNTED vmcnt waits instead of the LDS flags -- every VMEM
+// instruction of a wave is counted (`issued`), a unit remembers the count at its issue and is awaited with
+// vmcnt(issued - mark), which allows the epilogue's stores to stay outstanding behind it.  That is only correct if loads and
+// stores retire in issue order (what LLVM's waitcnt insertion assumes on gfx9, and what tools/probe_flag.hip mode 1 did not
+// contradict in 36 million checked slots; the round-2 report of out-of-order retirement may have been a miscount).
+template <int DT, int MODE, bool FLAGS = true>
 __global__ __launch_bounds__(512, 2) void k_gemm_ps(GemmKParams p, int tiles_total, unsigned c_bytes, unsigned res_bytes) {
   constexpr int BM = 128, BN = 320, KT = 64;
   constexpr int TM = 4, TN = 5;
@@ -250,7 +255,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ps(GemmKParams p, int tiles_tot
     }
   };
 
+  int mark_u[4] = {0, 0, 0, 0};  // FLAGS == false: `issued` right after the unit in flag slot s
   auto issue_flag = [&](int slot, int seqno) __attribute__((always_inline)) {
+    if (!FLAGS) {
+      if (slot == 0) mark_u[0] = issued;
+      else if (slot == 1) mark_u[1] = issued;
+      else if (slot == 2) mark_u[2] = issued;
+      else mark_u[3] = issued;
+      return;
+    }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_seq, (__attribute__((address_space(3))) void*)(my_flags + slot * 256), 4, 0u, (unsigned)(seqno & 1023) * 4u, 0, 0);
     issued += 1;
   };
@@ -321,12 +334,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ps(GemmKParams p, int tiles_tot
   // earlier in the phase (behind the fragment reads); the slow path re-reads with a short sleep and gives up after ~2^20
   // polls (a hung wave would take the whole device down; wrong results are caught by the tests, a hang is not).
   auto flag_begin = [&](int slot) __attribute__((always_inline)) -> unsigned {
+    if (!FLAGS) return 0u;
     unsigned fv;
     const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(my_flags + slot * 256);
     asm volatile("ds_read_b32 %0, %1" : "=v"(fv) : "v"(addr) : "memory");
     return fv;
   };
   auto flag_finish = [&](int slot, int seqno, unsigned fv) __attribute__((always_inline)) {
+    if (!FLAGS) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int n = issued - (slot == 0 ? mark_u[0] : slot == 1 ? mark_u[1] : slot == 2 ? mark_u[2] : mark_u[3]);
+      if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // the steady state: one A/B0 unit (4) and one B1 unit (3) younger
+      else ca_ps_vm_wait(n);
+      return;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fv)::"memory");
     const unsigned want = (unsigned)(seqno & 1023);
     if ((unsigned)__builtin_amdgcn_readfirstlane(fv) == want) return;
@@ -431,6 +452,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ps(GemmKParams p, int tiles_tot
     const f32x4 q0 = *reinterpret_cast<const f32x4*>(smem_b + RS_BASE + row * 32), q1 = *reinterpret_cast<const f32x4*>(smem_b + RS_BASE + row * 32 + 16);
     const float a = (((0.f + q0[0]) + q0[2]) + q1[0]) + q1[2], b = (((0.f + q0[1]) + q0[3]) + q1[1]) + q1[3];  // (quarters in order)
     if (m < p.m) *reinterpret_cast<float2*>(p.row_sums + ((int64_t)m * tiles_n + rs_tn) * 2) = make_float2(a, b);
+    // (NOT counted in `issued`: the compiler may branch around the store when no lane is active; an uncounted store only makes
+    //  the counted waits of the FLAGS == false variant one operation stricter, a phantom one would make them too weak)
   };
 
   // ---- the epilogue of one tile, from the accumulators (see the header)
@@ -572,6 +595,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ps(GemmKParams p, int tiles_tot
           else __builtin_amdgcn_raw_buffer_store_b64((u32x2){w[0], w[1]}, rs_c, rowoff[i] + (unsigned)(64 + 4 * g) * 2u, 0, 0);
         }
       }
+      issued += 3 * TM;
     } else {
       // GEGLU: weight rows interleaved (h, g); MFMA tiles 0..3 interleaved so that a lane holds 16 consecutive weight rows
       // = 8 consecutive output columns; tile 4 keeps 2 outputs per lane
@@ -593,6 +617,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ps(GemmKParams p, int tiles_tot
         __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[0], w[1], w[2], w[3]}, rs_c, rowoff[i] + (unsigned)(8 * g) * 2u, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(w[4], rs_c, rowoff[i] + (unsigned)(32 + 2 * g) * 2u, 0, 0);
       }
+      issued += 2 * TM;
     }
     if (p.row_sums) {
       // sum over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48 hold pieces of one row), then one lane

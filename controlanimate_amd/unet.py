@@ -409,6 +409,17 @@ class UNet3DConditionModel(HipModelMixin, nn.Module):
         for blk in (self.down_blocks[1:] if shared else self.down_blocks):
             x, outs = blk(x, ctx)
             skips += outs
+        if callable(down_residuals) and getattr(down_residuals, "fuse", False):
+            # fused ControlNet adds: the zero convolutions take the skips / the mid-block output as their residual operand and
+            # return `sample + residual` (MultiControlNetResidualsPipeline.residuals_nhwc_async, `fuse_images`)
+            x = self.mid_block(x, ctx)
+            skips, x = down_residuals(skips, x)
+            for blk in self.up_blocks:
+                n = len(blk.resnets)
+                x = blk(x, skips[-n:], ctx)
+                skips = skips[:-n]
+            x = self.conv_norm_out.run(x, frames_per_stat=ctx.gn_frames_per_stat, act=K.ACT_SILU)
+            return self.conv_out.run(x, out_f32=True)
         if callable(down_residuals):  # MultiControlNetResidualsPipeline.residuals_nhwc_async: join the side stream
             down_residuals, mid_residual = down_residuals()
         if down_residuals is not None:

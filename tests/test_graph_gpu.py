@@ -134,3 +134,68 @@ def test_pipeline_graph_persists_across_windows(scenario):
     # the windows really differ (the refresh is not a no-op)
     per = len(runs[0]) // 3
     assert not torch.equal(runs[0][per - 1], runs[0][2 * per - 1])
+
+
+def test_fused_controlnet_adds_equal_the_separate_adds():
+    """The reference's 13 `sample + residual` adds (unet.py:567-576, 584-585) inside the zero convolutions' epilogues
+    (residuals_nhwc_async(fuse_images=...)) == 13 separate ca_add_bcast passes, bit for bit with one ControlNet (the zero
+    convolution rounds its output to the activation type before the residual operand is added, exactly as the stored
+    residual was rounded) through the whole loop."""
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+    from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.schedulers import get_scheduler
+    from tests.test_pipeline_gpu import build
+    ucfg, uw, unet, ccfg, cws, nets = build("v2", seed=71, n_controlnets=1)
+    f, hw = 8, 8
+    g = torch.Generator().manual_seed(29)
+    pos, neg = torch.randn(1, 77, 768, generator=g) * 0.5, torch.randn(1, 77, 768, generator=g) * 0.5
+    hints = torch.rand(f, 3, 8 * hw, 8 * hw, generator=g)
+    lat = torch.randn(1, 4, f, hw, hw, generator=g)
+    outs = []
+    for fuse in (False, True):
+        pipe = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet,
+                                        scheduler=get_scheduler("DDIMScheduler", **NOISE_SCHEDULER_KWARGS)).to(DEV)
+        assert pipe.fuse_controlnet_adds is True  # the default
+        pipe.fuse_controlnet_adds = fuse
+        cn = MultiControlNetResidualsPipeline(["n0"], [0.8], use_lcm=False, controlnets=nets, device=DEV)
+        out = pipe(video_length=f, input_frames=None, height=8 * hw, width=8 * hw, num_inference_steps=3, strength=1.0,
+                   guidance_scale=7.5, generator=torch.Generator(device="cpu").manual_seed(3), latents=lat.clone(),
+                   multicontrolnetresiduals_pipeline=cn, prompt_embeds=pos, negative_prompt_embeds=neg, use_lcm=False,
+                   guess_mode=False, control_images={"n0": [h for h in hints]}, output_type="latent").videos
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_fused_controlnet_adds_two_nets_within_rounding():
+    """Two ControlNets: fused = round(round(s1 z1) + round(round(s0 z0) + skip)), separate = round(skip + round(round(s1 z1)
+    + round(s0 z0))) -- the same three terms associated differently, so every element agrees within a few fp16 ulps of
+    the largest term (and the two are NOT expected to be bit-identical)."""
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from tests.test_pipeline_gpu import build
+    ucfg, uw, unet, ccfg, cws, nets = build("v2", seed=72, n_controlnets=2)
+    f, hw = 8, 8
+    g = torch.Generator().manual_seed(31)
+    cn = MultiControlNetResidualsPipeline(["n0", "n1"], [0.8, 0.6], use_lcm=False, controlnets=nets, device=DEV)
+    cn.prep_control_images([h for h in torch.rand(f, 3, 8 * hw, 8 * hw, generator=g)], do_classifier_free_guidance=True, guess_mode=False)
+    prompt = (torch.randn(2, 77, 768, generator=g) * 0.5).to(DEV)
+    x = torch.randn(2 * f, hw, hw, nets[0].conv_in.cin_pad, generator=g).half().to(DEV)
+    t = torch.full((1,), 480.0, device=DEV)
+    bodies = cn.controlnet.forward_bodies(x, t, prompt, cn.prep_images, cn.cond_scale, False)
+    base_d = [(torch.randn(o.shape, generator=g) * 0.7).half().to(DEV) for o in bodies[0][0]]
+    base_m = (torch.randn(bodies[0][1].shape, generator=g) * 0.7).half().to(DEV)
+    fd, fm = cn.controlnet.finish(bodies, (base_d, base_m))
+    sd, sm = cn.controlnet.finish(bodies, None)
+    torch.cuda.synchronize()
+    assert len(fd) == len(sd) == 12
+    d0, m0 = nets[0].apply_zero_convs(*bodies[0], None)  # the first net's term alone: the intermediate sums' magnitude
+    for a, s_, r, r0 in zip((*fd, fm), (*base_d, base_m), (*sd, sm), (*d0, m0)):
+        sep = K.add_bcast(s_, r)
+        assert torch.isfinite(a).all() and r.float().abs().max() > 1e-3  # (the random zero convolutions are not zero)
+        mags = [s_.float().abs(), r.float().abs(), a.float().abs(), r0.float().abs(), (r.float() - r0.float()).abs(), (r0.float() + s_.float()).abs()]
+        scale = torch.stack(mags).amax(0).clamp_min(1e-3)
+        ulps = ((a.float() - sep.float()).abs() / (scale * 2.0 ** -10)).max().item()
+        assert ulps <= 3.0, ulps
