@@ -100,23 +100,39 @@ def _mkl(src: np.ndarray, ref: np.ndarray) -> np.ndarray:
     return ((x - mx) @ t + my).reshape(src.shape)
 
 
-def match_colors(frames: Sequence, ref_frame) -> List:
+def _minmax(a: np.ndarray) -> np.ndarray:
+    """color_matcher's `Normalizer.norm_fun`: (x - min) / (max - min) over the WHOLE array (all channels together);
+    a constant array is returned unchanged."""
+    lo, hi = float(a.min()), float(a.max())
+    return (a - lo) / (hi - lo) if hi != lo else a
+
+
+def match_colors(frames: Sequence, ref_frame, normalize: bool = True) -> List:
     """modules/utils.py:116-130: every frame is colour-matched to `ref_frame` with the compound 'hm-mkl-hm'
-    (histogram matching, then the Monge-Kantorovich linear transfer, then histogram matching again) on [0,1] floats,
-    and written back as uint8.  The reference delegates to the `color_matcher` package (absent here: this restatement
-    is unpinned against it; the property tests are in tests/test_vid2vid_host.py)."""
-    ref = _to_np(ref_frame).astype(np.float64) / 255.0
+    (histogram matching, then the Monge-Kantorovich linear transfer, then histogram matching again) and written back
+    as uint8.  The reference wraps the reference frame and every source frame in `Normalizer(...).type_norm()` and the
+    result in `Normalizer(...).uint8_norm()` (:122, :125, :127) -- min-max normalisations of the `color_matcher`
+    package: the transfer therefore targets the CONTRAST-STRETCHED reference frame and its result is stretched to the
+    full 0..255 range again (`normalize=True`, the default; `False` = plain /255 and clip, the round-2 behaviour).
+    The package is absent here: this restatement follows its published source and is unpinned against it; the property
+    tests are in tests/test_vid2vid_host.py."""
+    ref = _to_np(ref_frame).astype(np.float64)
+    ref = _minmax(ref) if normalize else ref / 255.0
     out = []
     for fr in frames:
-        x = _to_np(fr).astype(np.float64) / 255.0
+        x = _to_np(fr).astype(np.float64)
+        x = _minmax(x) if normalize else x / 255.0
         y = _hist_match(_mkl(_hist_match(x, ref), ref), ref)
+        if normalize:
+            y = _minmax(y)
         out.append(_like(np.clip(np.round(y * 255.0), 0, 255).astype(np.uint8), fr))
     return out
 
 
 class FFMPEGProcessor:
     """modules/utils.py:87-113: a child process whose stdin / stdout carries raw frames.  `read(count)` returns a uint8
-    array of up to `count` bytes, `write(array)` sends its bytes, `close()` ends the input."""
+    array of up to `count` bytes, `write(array)` sends its bytes, `close()` ends the input.  `cmd` is an argv list
+    (ffmpeg_reader_cmd / ffmpeg_writer_cmd; no shell) or, as in the reference, a caller-supplied shell string."""
 
     def __init__(self, cmd, std_in: bool = False, std_out: bool = False):
         from subprocess import PIPE, Popen
@@ -134,17 +150,21 @@ class FFMPEGProcessor:
         return self.process.wait()
 
 
-def ffmpeg_reader_cmd(path: str, width: int, height: int, fps: float, start_time: str = "00:00:00", end_time: Optional[str] = None) -> str:
-    """The decoder command of scripts/vid2vid.py:93-106: scaled raw rgb24 frames on stdout."""
-    to = f" -to {end_time}" if end_time else ""
-    return (f'ffmpeg -loglevel error -ss {start_time}{to} -i "{path}" -vf "fps={fps},scale={width}:{height}" '
-            f"-f rawvideo -pix_fmt rgb24 -")
+def ffmpeg_reader_cmd(path: str, width: int, height: int, fps: float, start_time: str = "00:00:00", end_time: Optional[str] = None,
+                      ffmpeg_path: str = "ffmpeg") -> List[str]:
+    """The decoder command of scripts/vid2vid.py:93-106: scaled raw rgb24 frames on stdout.  An argv LIST (run without a
+    shell): a file name with quotes, `$()` or `;` in it stays a file name -- the reference interpolates it into a shell
+    string."""
+    cmd = [str(ffmpeg_path), "-loglevel", "error", "-ss", str(start_time)]
+    if end_time:
+        cmd += ["-to", str(end_time)]
+    return cmd + ["-i", str(path), "-vf", f"fps={fps},scale={width}:{height}", "-f", "rawvideo", "-pix_fmt", "rgb24", "-"]
 
 
-def ffmpeg_writer_cmd(path: str, width: int, height: int, fps: float, crf: int = 17) -> str:
-    """The encoder command of scripts/vid2vid.py:120-136: raw rgb24 frames on stdin -> h264."""
-    return (f"ffmpeg -loglevel error -y -f rawvideo -pix_fmt rgb24 -s {width}x{height} -r {fps} -i - "
-            f'-c:v libx264 -pix_fmt yuv420p -crf {crf} "{path}"')
+def ffmpeg_writer_cmd(path: str, width: int, height: int, fps: float, crf: int = 17, ffmpeg_path: str = "ffmpeg") -> List[str]:
+    """The encoder command of scripts/vid2vid.py:120-136: raw rgb24 frames on stdin -> h264 (argv list, no shell)."""
+    return [str(ffmpeg_path), "-loglevel", "error", "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{width}x{height}", "-r", str(fps),
+            "-i", "-", "-c:v", "libx264", "-pix_fmt", "yuv420p", "-crf", str(crf), str(path)]
 
 
 def frames_from_pipe(reader: FFMPEGProcessor, width: int, height: int) -> Iterator:

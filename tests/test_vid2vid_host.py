@@ -105,14 +105,24 @@ def test_match_colors_hm_mkl_hm_properties():
     rng = np.random.default_rng(0)
     ref = np.clip(rng.normal([150, 90, 60], [30, 20, 10], (48, 64, 3)), 0, 255).astype(np.uint8)
     src = np.clip(rng.normal([80, 120, 200], [15, 35, 25], (48, 64, 3)), 0, 255).astype(np.uint8)
-    out = match_colors([src], ref)[0]
+    out = match_colors([src], ref, normalize=False)[0]
     assert out.dtype == np.uint8 and out.shape == src.shape
     # marginal statistics of every channel move onto the reference's (the final step is a histogram match)
     for c in range(3):
         assert abs(out[..., c].mean() - ref[..., c].mean()) < 1.5 and abs(out[..., c].std() - ref[..., c].std()) < 1.5
         assert np.abs(np.sort(out[..., c].ravel()).astype(float) - np.sort(ref[..., c].ravel())).mean() < 1.0
     # matching an image to itself changes nothing (up to one grey level of float round-off); MKL maps the covariance exactly
-    assert np.abs(match_colors([ref], ref)[0].astype(int) - ref.astype(int)).max() <= 1
+    assert np.abs(match_colors([ref], ref, normalize=False)[0].astype(int) - ref.astype(int)).max() <= 1
+    # the default follows the reference's Normalizer wrappers (utils.py:122-127): the target is the min-max stretched
+    # reference frame and the result spans 0..255
+    dim = (ref.astype(np.float64) * 0.5 + 40).astype(np.uint8)  # a reference frame that does not span the range
+    stretched = np.round((dim.astype(np.float64) - dim.min()) / (float(dim.max()) - float(dim.min())) * 255)
+    outn = match_colors([src], dim)[0]
+    assert outn.min() == 0 and outn.max() == 255
+    for c in range(3):
+        assert abs(outn[..., c].mean() - stretched[..., c].mean()) < 2.5
+    # (<= 3: the MKL step perturbs equal grey levels by 1e-16, which splits their ties in the second histogram match)
+    assert np.abs(match_colors([dim], dim)[0].astype(int) - stretched.astype(int)).max() <= 3
     x, y = src.astype(np.float64) / 255, ref.astype(np.float64) / 255
     t = _mkl(x, y).reshape(-1, 3)
     assert np.allclose(np.cov(t, rowvar=False), np.cov(y.reshape(-1, 3), rowvar=False), atol=1e-8)
@@ -138,7 +148,11 @@ def test_ffmpeg_pipe_class_and_prefetch():
     got = list(prefetch(frames_from_pipe(proc, w, h), depth=2))
     assert proc.process.wait() == 0
     assert len(got) == n and all(np.array_equal(np.asarray(a), b) for a, b in zip(got, frames))
-    assert "rawvideo" in ffmpeg_reader_cmd("in.mp4", 512, 512, 15) and "-s 512x512" in ffmpeg_writer_cmd("out.mp4", 512, 512, 15)
+    rd, wr = ffmpeg_reader_cmd('in "$(x)".mp4', 512, 512, 15, end_time="00:00:05"), ffmpeg_writer_cmd("out;rm.mp4", 512, 512, 15)
+    assert isinstance(rd, list) and 'in "$(x)".mp4' in rd and "rawvideo" in rd and rd[rd.index("-to") + 1] == "00:00:05"
+    assert isinstance(wr, list) and wr[-1] == "out;rm.mp4" and wr[wr.index("-s") + 1] == "512x512"
+    echo = FFMPEGProcessor(["printf", "%s", "a;b"], std_out=True)  # an argv list runs without a shell
+    assert bytes(echo.read(16)) == b"a;b" and echo.close() == 0
 
     def boom():
         yield 1

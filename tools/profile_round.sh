@@ -25,3 +25,6 @@ Q=$(find "$OUT/sq" -name "*counter_collection.csv" | head -1); [ -n "$Q" ] && py
 M=$(find "$OUT/mfma" -name "*counter_collection.csv" | head -1); [ -n "$M" ] && python3 tools/pmc_mfma_summary.py "$M" > profiles/${TAG}_mfma_util.txt
 cp profiles/${TAG}_* gpurun_out/ 2>/dev/null
 ls -la profiles/${TAG}_*
+# the raw traces stay on the box: gpurun merges at most 64 MiB back
+rm -rf "$OUT/trace" "$OUT/trace1s" "$OUT/fetch" "$OUT/write" "$OUT/sq" "$OUT/mfma"
+du -sh gpurun_out
