@@ -180,7 +180,7 @@ def kernel_display_name(family: str) -> str:
     return f"k_gemm_dma<{family}>"
 
 
-PMC_SUMMARIES = ("round2_pmc_traffic.json", "round1_pmc_traffic.json")
+PMC_SUMMARIES = ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
 
 
 def pmc_traffic(kernel_prefix: str, workload_key: str, dtype: str):

@@ -23,7 +23,9 @@ for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0.0))):
     fa, wa = f[k] / max(nf[k], 1), w.get(k, 0.0) / max(nw.get(k, 0), 1)
     kern[k] = {"launches": nf[k], "fetch_size_kb_avg": round(fa, 1), "write_size_kb_avg": round(wa, 1),
                "hbm_bytes_per_launch": int((2 * fa + wa) * 1024)}
-steps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+# denoise steps executed in the pass = launches of the sampler kernel (one per step: the pipeline-driven bench runs a whole
+# first window before its timed region); argv[5] overrides
+steps = int(sys.argv[5]) if len(sys.argv) > 5 and int(sys.argv[5]) > 0 else (nf.get("k_cfg_scheduler_step", 0) or 3)
 total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kern.values())
 print(json.dumps({
     "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-roofline --no-overlap --no-graph",

@@ -20,7 +20,7 @@ find "$OUT" -name "*.csv" | head -40
 S=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp "$S" profiles/${TAG}_bench_kernel_stats.csv && cp "$OUT/trace_bench.json" profiles/${TAG}_bench_kernel_stats_run.json
 S=$(find "$OUT/trace1s" -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp "$S" profiles/${TAG}_bench_kernel_stats_single_stream.csv
 F=$(find "$OUT/fetch" -name "*counter_collection.csv" | head -1); W=$(find "$OUT/write" -name "*counter_collection.csv" | head -1)
-[ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_traffic_json.py "$F" "$W" config2 fp16 3 > profiles/${TAG}_pmc_traffic.json
+[ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_traffic_json.py "$F" "$W" config2 fp16 > profiles/${TAG}_pmc_traffic.json
 Q=$(find "$OUT/sq" -name "*counter_collection.csv" | head -1); [ -n "$Q" ] && python3 tools/pmc_sq_summary.py "$Q" > profiles/${TAG}_pmc_sq_summary.txt
 M=$(find "$OUT/mfma" -name "*counter_collection.csv" | head -1); [ -n "$M" ] && python3 tools/pmc_mfma_summary.py "$M" > profiles/${TAG}_mfma_util.txt
 cp profiles/${TAG}_* gpurun_out/ 2>/dev/null
