@@ -476,6 +476,7 @@ enum PlanKind {
   PK_DMA_SPLITK,  // k_gemm_dma<128,128> K ranges + k_splitk_reduce
   PK_REG,         // k_gemm<bm, bn>: register-staged (channel counts the DMA path cannot take)
   PK_PS,          // persistent streaming kernel, 128 x 320 tiles (ca_gemm_ps.h)
+  PK_PQ,          // persistent streaming kernel, 256 x 320 tiles / 128 x 80 wave tiles (ca_gemm_pq.h)
   PK_EXP,         // experiment builds only: `exp` selects (see launch_gemm)
 };
 struct GemmPlan {
@@ -502,7 +503,15 @@ inline bool ps_capable(const GemmKParams& p) {
          (!p.rowbias || p.rows_per_group % 64 == 0) && !(p.geglu && (p.res || p.row_sums)) && p.post == 1.f && p.act == CA_ACT_NONE;
 }
 
-inline GemmPlan plan_gemm(const GemmKParams& p, int mode) {
+// 256 x 320 streaming kernel (ca_gemm_pq.h): bias, row bias, alpha and residual only
+inline bool pq_capable(const GemmKParams& p, int mode) {
+  // (packed row state of the convolution gather: tap-0 pixel index in 24 signed bits, middle tap always inside the image)
+  const bool conv_ok = mode != 1 || (p.pad_lo == 1 && p.ups == 0 && p.hin >= 2 && p.win >= 2 && (int64_t)(p.m / (p.hout * p.wout) + 1) * p.hin * p.win < (1 << 23) &&
+                                     (p.hout - 1) * p.stride < p.hin && (p.wout - 1) * p.stride < p.win);
+  return ps_capable(p) && !p.geglu && !p.ln_colsum && !p.ln_stats && !p.row_sums && (mode == 1 || p.c2 == 0) && (!p.rowbias || p.rows_per_group % 128 == 0) && conv_ok;
+}
+
+inline GemmPlan plan_gemm(const GemmKParams& p, int mode, bool allow_pq = true) {
   GemmPlan g{};
   g.splits = 1;
   const int kc = p.c1 + p.c2;
@@ -542,6 +551,23 @@ inline GemmPlan plan_gemm(const GemmKParams& p, int mode) {
   // outputs where four co-resident 128x128 blocks already hide their epilogues (32768x1920x640 116 vs 107) and on every
   // convolution (-10..-25%).  Hence: dense, 2..20 K tiles, at least one tile per CU, GEGLU or at most four column tiles.
   // CA_GEMM_PS (experiment builds): 0 = never, 1 = every launch it can take, 2 = the same except the weight-resident kernel's.
+  // 256 x 320 streaming kernel (ca_gemm_pq.h): 128 x 80 wave tiles take a quarter of the 128 x 320 kernels' LDS-port and
+  // global -> LDS traffic per FLOP; it needs one tile per CU and a long K loop, and has no LayerNorm / GEGLU / row-sum epilogue.
+  // Measured against the kernel each shape had before (tools/ps_check.py --time, one process, us): dense 32768x640x2560 117 vs
+  // 124, 131072x320x1280 146 vs 158, 32768x640x640 43 vs 52; convolutions at 32x32 latents 640->640 258 vs 290, 1280->640 468
+  // vs 556, 1280->1280 945 vs 963; behind where the 256-row tiles leave CUs idle (M = 8192: 128 tiles, 154 vs 109) and on the
+  // 64x64-latent convolutions (320->320 296 vs 265, 640->640 1016 vs 1007).
+  // CA_GEMM_PQ (experiment builds): 0 = never, 1 = every launch it can take
+  static const int pq_env = CA_KNOB("CA_GEMM_PQ", -1);
+  if (allow_pq && pq_env != 0 && pq_capable(p, mode)) {
+    const int64_t tiles = (int64_t)ceil_div_i(p.m, 256) * (p.n / 320);
+    const bool dflt = mode == 1 ? (tiles >= 256 && tiles < 512) : (tiles >= 256 && nt >= 8 && !wres_eligible(p));
+    if ((pq_env < 0 && dflt) || pq_env == 1) {
+      g.kind = PK_PQ;
+      g.bm = 256, g.bn = 320, g.tiles = (unsigned)tiles;
+      return g;
+    }
+  }
   static const int ps_env = CA_KNOB("CA_GEMM_PS", -1);
   if (ps_env != 0 && ps_capable(p)) {
     const int64_t tiles = (int64_t)ceil_div_i(p.m, 128) * (p.n / 320);
@@ -637,7 +663,7 @@ inline GemmPlan plan_gemm(const GemmKParams& p, int mode) {
 // tile kernels do; the answer is about the launch the arguments get WITHOUT the pointer.
 inline bool row_sums_capable(GemmKParams p) {
   p.row_sums = nullptr;
-  const int k = plan_gemm(p, 0).kind;
+  const int k = plan_gemm(p, 0, /*allow_pq=*/false).kind;  // (the 256 x 320 kernel cannot; with the pointer set the plan skips it)
   return (k == PK_PP2 || k == PK_PS) && !p.geglu && !p.out_f32;
 }
 
@@ -646,6 +672,7 @@ inline void plan_label(const GemmPlan& g, char* buf, int len) {
     case PK_WRES: snprintf(buf, len, "wres160"); break;
     case PK_PP2: snprintf(buf, len, "pp128x320"); break;
     case PK_PS: snprintf(buf, len, "ps128x320"); break;
+    case PK_PQ: snprintf(buf, len, "pq256x320"); break;
     case PK_PP2_SPLITK: snprintf(buf, len, "pp128x320_splitk%d", g.splits); break;
     case PK_DMA: snprintf(buf, len, "%dx%d%s", g.bm, g.bn, g.nbuf == 2 ? "_db" : ""); break;
     case PK_DMA_SPLITK: snprintf(buf, len, "128x128_splitk%d", g.splits); break;
@@ -662,6 +689,7 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
     case PK_WRES: return ca_launch_gemm_pp(p, DT, MODE, 160, 0u, st);
     case PK_PP2: return ca_launch_gemm_pp(p, DT, MODE, 320, g.tiles, st);
     case PK_PS: return ca_launch_gemm_pp(p, DT, MODE, 322, g.tiles, st);
+    case PK_PQ: return ca_launch_gemm_pp(p, DT, MODE, 323, g.tiles, st);
     case PK_PP2_SPLITK: {
       GemmKParams q = p;
       q.splits = g.splits;

@@ -7,6 +7,7 @@ using namespace ca_gemm_detail;
 #include "ca_gemm_pp2.h"
 #include "ca_gemm_wres.h"
 #include "ca_gemm_ps.h"
+#include "ca_gemm_pq.h"
 #ifdef CA_EXPERIMENTS  // round-2 experiments that never became defaults: not in the product library
 #include "ca_gemm_pp.h"
 #include "ca_gemm_pp3.h"
@@ -66,6 +67,41 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
     return CA_OK;
   }
 #endif
+  if (bn == 323) {  // persistent streaming kernel, 256 x 320 tiles (ca_gemm_pq.h)
+    const unsigned c_bytes = (unsigned)((((int64_t)p.m - 1) * p.ldc + p.n) * 2);
+    const unsigned res_bytes = p.res ? (unsigned)((((int64_t)p.m - 1) * p.ld_res + p.n) * 2) : 0u;
+    const unsigned grid = tiles < (unsigned)cu_count() ? tiles : (unsigned)cu_count();
+#ifdef CA_EXPERIMENTS
+    if (p.dbg == 9) {  // timing experiment: shader-clock stamps of block 0, printed to stderr (first launch only)
+      static unsigned long long* dbuf = nullptr;
+      if (!dbuf && hipMalloc(&dbuf, 4096 * 8) != hipSuccess) return CA_ERR_LAUNCH;
+      (void)hipMemsetAsync(dbuf, 0, 4096 * 8, st);
+      GemmKParams q = p;
+      q.partial = reinterpret_cast<float*>(dbuf);
+      hipLaunchKernelGGL((k_gemm_pq<DT, MODE>), dim3(grid), dim3(512), 0, st, q, (int)tiles, c_bytes, res_bytes);
+      (void)hipStreamSynchronize(st);
+      static int printed = 0;
+      if (printed++ < 1) {
+        static unsigned long long host[4096];
+        (void)hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost);
+        for (int g = 0; g < 2; ++g) {
+          fprintf(stderr, "[pq stamps group %d, %dx%dx%d] tag:delta_cycles ...\n", g, p.m, p.n, (p.c1 + p.c2) * p.taps);
+          unsigned long long prev = host[g * 2048];
+          for (int i = 0; i < 1000 && host[g * 2048 + 2 * i]; ++i) {
+            fprintf(stderr, "%llu:%llu ", host[g * 2048 + 2 * i + 1], host[g * 2048 + 2 * i] - prev);
+            prev = host[g * 2048 + 2 * i];
+            if (host[g * 2048 + 2 * i + 1] == 8) fprintf(stderr, "| ");
+            if (host[g * 2048 + 2 * i + 1] == 10) fprintf(stderr, "\n");
+          }
+          fprintf(stderr, "\n");
+        }
+      }
+      return CA_OK;
+    }
+#endif
+    hipLaunchKernelGGL((k_gemm_pq<DT, MODE>), dim3(grid), dim3(512), 0, st, p, (int)tiles, c_bytes, res_bytes);
+    return CA_OK;
+  }
   if (bn == 322) {  // persistent streaming kernel, 128 x 320 tiles (ca_gemm_ps.h)
     const int64_t ncols = p.geglu ? p.n / 2 : p.n;
     const unsigned c_bytes = (unsigned)((((int64_t)p.m - 1) * p.ldc + ncols) * 2);

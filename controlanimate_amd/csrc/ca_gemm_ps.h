@@ -400,9 +400,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ps(GemmKParams p, int tiles_tot
       const int m = m0 + wr * 64 + i * 16 + l15o;
       const unsigned rowoff = m < p.m ? (unsigned)m * (unsigned)p.ld_res * 2u + (unsigned)(n0 + wc * 80) * 2u : OOB_V;  // (out of range reads 0)
       const unsigned o0 = rowoff + (unsigned)(8 * go) * 2u, o1 = rowoff + (unsigned)(32 + 8 * go) * 2u, o2 = rowoff + (unsigned)(64 + 4 * go) * 2u;
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(res16[i][0]) : "v"(o0), "s"(rs_res) : "memory");
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(res16[i][1]) : "v"(o1), "s"(rs_res) : "memory");
-      asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(res8[i]) : "v"(o2), "s"(rs_res) : "memory");
+      // (one statement, led by s_nop 4: the descriptor may just have been restored from an SGPR spill lane by v_readlane, and a
+      //  VMEM instruction needs five wait states after a VALU write of an SGPR it reads -- hipcc's hazard recogniser does not
+      //  look inside inline asm; found in ca_gemm_pq.h, where it faulted.  Early-clobber outputs: a load's data may return
+      //  before the next one has read its address register.)
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %3, %6, 0 offen\n\tbuffer_load_dwordx4 %1, %4, %6, 0 offen\n\tbuffer_load_dwordx2 %2, %5, %6, 0 offen"
+                   : "=&v"(res16[i][0]), "=&v"(res16[i][1]), "=&v"(res8[i])
+                   : "v"(o0), "v"(o1), "v"(o2), "s"(rs_res)
+                   : "memory");
     }
     issued += 3 * TM;
     mark_res = issued;

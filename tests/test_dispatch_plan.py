@@ -60,7 +60,7 @@ def conv_label(capi, images, h, cin, cout, *, cin2=0, stride=1, upsample=0, work
 
 # (M, N, K, keyword flags) -> label.  Rows = the dense launches of one config-2 denoise step (ControlNet + UNet3D,
 # `bench.py --shapes`), largest time share first.  Labels: wres160 = weight-resident K = 320 kernel, ps128x320 = persistent
-# streaming kernel (round 3), pp128x320 = ping-pong 128 x 320 tiles, BMxBN = k_gemm_dma tiles (_db: two LDS stages),
+# streaming kernel (round 3), pq256x320 = its 256 x 320 / 128 x 80-wave-tile sibling (round 3), pp128x320 = ping-pong 128 x 320 tiles, BMxBN = k_gemm_dma tiles (_db: two LDS stages),
 # _splitkS = S K ranges + reduce, reg_ = register-staged fallback.
 GEMMS = [
     ((131072, 2560, 320, dict(geglu=1, ln="inline")), "wres160"),     # FF projection + GEGLU, 64x64 latents
@@ -69,13 +69,13 @@ GEMMS = [
     ((131072, 960, 320, dict(ln="inline")), "wres160"),               # q|k|v
     ((32768, 5120, 640, dict(geglu=1, ln=2)), "ps128x320"),
     ((32768, 640, 640, dict(res=True, row_sums=True)), "ps128x320"),
-    ((32768, 640, 640, dict()), "ps128x320"),
+    ((32768, 640, 640, dict()), "pq256x320"),
     ((32768, 1920, 640, dict(ln=2)), "128x128"),
     ((8192, 10240, 1280, dict(geglu=1, ln=4)), "ps128x320"),
     ((8192, 1280, 1280, dict(res=True, row_sums=True)), "ps128x320"),
     ((8192, 3840, 1280, dict(ln=4)), "128x128"),
-    ((131072, 320, 1280, dict(res=True)), "ps128x320"),               # FF out, 64x64 latents
-    ((32768, 640, 2560, dict(res=True)), "pp128x320"),
+    ((131072, 320, 1280, dict(res=True)), "pq256x320"),               # FF out, 64x64 latents
+    ((32768, 640, 2560, dict(res=True)), "pq256x320"),
     ((8192, 1280, 5120, dict(res=True)), "pp128x320"),
     ((2048, 1280, 1280, dict(res=True)), "128x64_db"),
     ((2048, 1280, 5120, dict(res=True, workspace=True)), "pp128x320_splitk4"),
@@ -84,24 +84,27 @@ GEMMS = [
     ((2048, 10240, 1280, dict(geglu=1, ln="stats")), "ps128x320"),
     ((131072, 320, 640, dict(k2=320)), "ps128x320"),                  # shortcut over the skip concat (K = 320 + 320)
     ((32, 1280, 320, dict()), "128x64_db"),                           # time embedding
+    ((32768, 640, 640, dict(row_sums=True)), "ps128x320"),            # the 256 x 320 kernel has no row-sum epilogue: the launch keeps the kernel that has
+    ((8192, 1280, 5120, dict(res=True)), "pp128x320"),                # 128 tiles of 256 x 320 would leave half the CUs idle
 ]
 
 # (images, H, Cin, Cout, keyword flags) -> label
 CONVS = [
     ((32, 64, 320, 320, dict()), "128x160"),
     ((32, 16, 1280, 1280, dict()), "pp128x320"),
-    ((32, 32, 640, 640, dict()), "128x128"),
+    ((32, 32, 640, 640, dict()), "pq256x320"),
     ((32, 8, 1280, 1280, dict()), "128x128_splitk6"),
     ((32, 8, 1280, 1280, dict(workspace=False)), "128x64_db"),
     ((32, 16, 2560, 1280, dict(cin2=1280)), "pp128x320"),
     ((32, 64, 640, 320, dict(cin2=320)), "128x160"),
     ((32, 64, 640, 640, dict(upsample=0)), "128x128"),
     ((32, 32, 1280, 1280, dict()), "128x128"),
-    ((32, 32, 1920, 640, dict(cin2=640)), "128x128"),
+    ((32, 32, 1920, 640, dict(cin2=640)), "pq256x320"),
     ((32, 64, 960, 320, dict(cin2=320)), "128x160"),
     ((32, 64, 320, 320, dict(stride=2)), "pp128x320"),                # Downsample: 32x32 outputs
     ((32, 16, 1280, 1280, dict(upsample=1)), "128x128"),              # Upsample: 32x32 outputs
     ((32, 64, 8, 320, dict()), "reg_128x64"),                         # conv_in (4 latent channels padded to 8)
+    ((32, 32, 640, 640, dict(upsample=1)), "128x128"),                # (the 256 x 320 kernel's gather has no upsampling)
 ]
 
 

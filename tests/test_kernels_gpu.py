@@ -582,3 +582,54 @@ def test_layernorm_statistics_handed_from_producer_to_consumer(m, c, dtype):
     # a shape the 128x320 kernel does not take: no sums, and asking for them in the C call is an error, not a fallback
     small = k.gemm(a[:256], w, row_sums=True)
     assert k.row_sums_of(small) is None
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_and_conv_256x320_streaming_kernel(dtype):
+    """ca_gemm_pq.h (256 x 320 tiles, 128 x 80 wave tiles; round 3): the launches the plan sends to it by default -- long-K
+    dense GEMMs and the 32x32-latent convolutions with one tile per CU -- with every epilogue it implements (bias, one and
+    two row-bias groups per tile, alpha, residual), ragged M, two-source and stride-2 gathers; each against an fp32
+    reference with the tiled kernels' rounding order, bit-for-bit repeatable, and on the kernel the case is about."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ps_check
+    k = _k()
+    tol = 2.5e-3 if dtype == torch.float16 else 1.5e-2
+    g = torch.Generator().manual_seed(5)
+
+    def rn(*s, scale=1.0):
+        return (torch.randn(*s, generator=g) * scale).to(DEV)
+
+    cases = []
+    for (m, n, kk) in [(32768, 640, 2560), (32768 - 40, 640, 640), (65536, 320, 1280)]:
+        a, w = rn(m, kk).to(dtype), rn(n, kk, scale=kk ** -0.5).to(dtype)
+        bias, res = rn(n), rn(m, n).to(dtype)
+        cases.append(("gemm", f"plain {m}x{n}x{kk}", dict(a=a, w=w)))
+        cases.append(("gemm", f"bias+res {m}x{n}x{kk}", dict(a=a, w=w, bias=bias, residual=res)))
+        cases.append(("gemm", f"rowbias(128)+res alpha {m}x{n}x{kk}", dict(a=a, w=w, bias=bias, rowbias=rn((m + 127) // 128, n), rows_per_group=128, residual=res, alpha=0.75)))
+        cases.append(("gemm", f"rowbias(1024) {m}x{n}x{kk}", dict(a=a, w=w, rowbias=rn((m + 1023) // 1024, n), rows_per_group=1024)))
+    for (img, h, ci, co, stride, c2) in [(32, 32, 640, 640, 1, 0), (32, 32, 640, 640, 1, 640), (37, 30, 320, 640, 1, 0), (32, 64, 320, 640, 2, 0)]:
+        x = rn(img, h, h, ci).to(dtype)
+        x2 = rn(img, h, h, c2).to(dtype) if c2 else None
+        w = rn(co, 3, 3, ci + c2, scale=(9 * (ci + c2)) ** -0.5).to(dtype)
+        ho = (h + 2 - 3) // stride + 1
+        cases.append(("conv", f"conv {img}x{h} {ci}+{c2}->{co} s{stride}", dict(x=x, x2=x2, w=w, stride=stride)))
+        full = dict(x=x, x2=x2, w=w, stride=stride, bias=rn(co), residual=rn(img, ho, ho, co).to(dtype))
+        if (ho * ho) % 128 == 0:  # (row-bias groups = images; the kernel takes multiples of 128 rows)
+            full.update(rowbias=rn(img, co), rows_per_group=ho * ho)
+        cases.append(("conv", f"conv+bias+rowbias+res {img}x{h} {ci}+{c2}->{co} s{stride}", full))
+    for kind, name, kw in cases:
+        k._plan_sink = labels = []
+        if kind == "conv":
+            call = dict(kw)
+            x, w = call.pop("x"), call.pop("w")
+            outs = [k.conv3x3(x, w, **call).clone() for _ in range(2)]
+            ref = ps_check.conv_reference(kw)
+        else:
+            outs = [k.gemm(**kw).clone() for _ in range(2)]
+            ref = ps_check.gemm_reference(kw)
+        k._plan_sink = None
+        assert set(labels) == {"pq256x320"}, (name, labels)
+        rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
+        assert torch.isfinite(outs[0].float()).all() and rel < tol, (name, rel)
+        assert torch.equal(outs[0], outs[1]), name

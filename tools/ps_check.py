@@ -5,7 +5,8 @@ bit-determinism, and timing at the benchmark shapes.  Needs the experiments libr
     CA_HIP_LIB=controlanimate_amd/csrc/libcontrolanimate_hip_exp.so CA_GEMM_PS=1 python tools/ps_check.py --check --time
     CA_HIP_LIB=controlanimate_amd/csrc/libcontrolanimate_hip_exp.so CA_GEMM_PS=0 python tools/ps_check.py --time     # the other kernels
 
-With --check every launch must report the plan label "ps128x320" (else the case does not test what it says)."""
+With --check every launch must report the plan label "ps128x320" (else the case does not test what it says).
+CA_GEMM_PQ=1 sends every launch the 256 x 320 kernel (ca_gemm_pq.h) can take to it (label "pq256x320"; the others keep theirs)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -70,6 +71,8 @@ def gemm_cases(dt):
         rpg = 64 * 3
         rb = rn((m + rpg - 1) // rpg, n)
         out.append((f"rowbias(192) + res {m}x{n}x{k}", dict(a=a, w=w, bias=bias, rowbias=rb, rows_per_group=rpg, residual=res)))
+        rb2 = rn((m + 255) // 256, n)
+        out.append((f"rowbias(256) + res alpha {m}x{n}x{k}", dict(a=a, w=w, bias=bias, rowbias=rb2, rows_per_group=256, residual=res, alpha=0.75)))
         st = torch.stack([a.float().mean(1), (a.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
         cs = w.float().sum(1).contiguous()
         out.append((f"LN fold (mean, rstd) {m}x{n}x{k}", dict(a=a, w=w, bias=bias, ln=(st, cs), residual=res, _ln_ref=st)))
@@ -132,7 +135,7 @@ def conv_reference(kw):
 
 def check():
     bad = 0
-    need_label = os.environ.get("CA_GEMM_PS", "0") not in ("0", "")
+    need_label = os.environ.get("CA_GEMM_PS", "0") not in ("0", "") and os.environ.get("CA_GEMM_PQ", "0") in ("0", "")
     for dt in (torch.float16, torch.bfloat16):
         tol = 2.5e-3 if dt == torch.float16 else 1.5e-2
         for kind, cases, ref_fn, fn in (("gemm", gemm_cases(dt), gemm_reference, K.gemm), ("conv", conv_cases(dt), conv_reference, K.conv3x3)):
