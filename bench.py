@@ -14,6 +14,8 @@ weights/inputs (no checkpoints exist offline).  Every rank runs its own window (
 sharding unit, weak scaling); weights are broadcast once over RCCL before timing.
 
 frames/sec = n_gpus * frames_per_window / (steps_per_window * sec_per_step), steps_per_window = 20.
+Default K = one whole window (the timed region begins at a window start and so contains the per-window work once per
+20 steps, the product's own ratio); W = 3 warm-up steps are the tail of the window before it.
 Prints one JSON line (rank 0).
 """
 from __future__ import annotations
@@ -56,7 +58,9 @@ CONFIGS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=0,
+                    help="timed steps K; default (0) = the steps of ONE window of the config (20 for config 2): the timed region begins at "
+                         "a window start, so a whole window holds the per-window work exactly once, as the product's loop does")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = the headline workload)")
     ap.add_argument("--frames", type=int, default=None, help="override the config's frames per window")
@@ -84,7 +88,10 @@ def parse():
                     help="multi-rank plumbing rehearsal WITHOUT the hot path (runs on a CPU box over gloo): rendezvous, "
                          "weight-arena broadcast, barriers, max-over-ranks timing, rank-0 JSON with `dry_run: true` and "
                          "`value: null`.  Never a measurement; used by tests/test_bench_launch.py")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps <= 0:
+        args.steps = int(CONFIGS[args.config]["steps"])
+    return args
 
 
 def _free_port() -> int:
