@@ -50,17 +50,20 @@ def _stale(out: str, deps: list[str]) -> bool:
 
 
 LIB_EXP = os.path.join(CSRC, "libcontrolanimate_hip_exp.so")
+LIB_STAMPS = os.path.join(CSRC, "libcontrolanimate_hip_stamps.so")  # --experiments --stamps: knobs + s_memtime stamps (tools/*_stamps.py)
 
 
-def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, experiments: bool = False, stamps: bool = False) -> str:
     hipcc = _hipcc()
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     jobs = []
     objs = []
-    objdir = os.path.join(CSRC, "build_exp") if experiments else CSRC
+    objdir = os.path.join(CSRC, "build_stamps" if stamps else "build_exp") if experiments else CSRC
     os.makedirs(objdir, exist_ok=True)
-    lib = LIB_EXP if experiments else LIB
+    lib = (LIB_STAMPS if stamps else LIB_EXP) if experiments else LIB
     xflags = ["-DCA_EXPERIMENTS"] if experiments else []
+    if stamps:
+        xflags.append("-DCA_STAMPS")
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
@@ -85,4 +88,4 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv, stamps="--stamps" in sys.argv))

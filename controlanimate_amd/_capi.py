@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CA_HIP_LIB") or os.path.join(_HERE, "csrc", "libcontr
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class CAHipUnavailable(RuntimeError):
@@ -96,6 +96,8 @@ SYMBOLS = {
     "ca_last_error": (C.c_char_p, []),
     "ca_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "ca_gemm_ln_inline_supported": (C.c_int, [C.POINTER(GemmArgs)]),
+    "ca_gemm_wants_finished_stats": (C.c_int, [C.POINTER(GemmArgs)]),
+    "ca_ln_finish_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "ca_gemm_workspace_bytes": (C.c_int64, [C.POINTER(GemmArgs)]),
     "ca_gemm_row_sums_parts": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_gemm_plan_name": (C.c_int, [C.POINTER(GemmArgs), C.c_char_p, C.c_int32]),

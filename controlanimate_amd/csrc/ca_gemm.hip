@@ -508,7 +508,9 @@ inline bool pq_capable(const GemmKParams& p, int mode) {
   // (packed row state of the convolution gather: tap-0 pixel index in 24 signed bits, middle tap always inside the image)
   const bool conv_ok = mode != 1 || (p.pad_lo == 1 && p.ups == 0 && p.hin >= 2 && p.win >= 2 && (int64_t)(p.m / (p.hout * p.wout) + 1) * p.hin * p.win < (1 << 23) &&
                                      (p.hout - 1) * p.stride < p.hin && (p.wout - 1) * p.stride < p.win);
-  return ps_capable(p) && !p.geglu && !p.ln_colsum && !p.ln_stats && !p.row_sums && (mode == 1 || p.c2 == 0) && (!p.rowbias || p.rows_per_group % 128 == 0) && conv_ok;
+  const bool epi1 = p.geglu || p.ln_colsum || p.ln_stats;  // the LayerNorm / GEGLU epilogue variant: dense, no residual
+  return ps_capable(p) && !p.row_sums && (mode == 1 || p.c2 == 0) && (!p.rowbias || p.rows_per_group % 128 == 0) && conv_ok &&
+         (!epi1 || (mode == 0 && !p.res && !p.rowbias && p.ln_parts == 0 && (!p.ln_colsum || p.ln_stats)));
 }
 
 inline GemmPlan plan_gemm(const GemmKParams& p, int mode, bool allow_pq = true) {
@@ -553,16 +555,23 @@ inline GemmPlan plan_gemm(const GemmKParams& p, int mode, bool allow_pq = true) 
   // CA_GEMM_PS (experiment builds): 0 = never, 1 = every launch it can take, 2 = the same except the weight-resident kernel's.
   // 256 x 320 streaming kernel (ca_gemm_pq.h): 128 x 80 wave tiles take a quarter of the 128 x 320 kernels' LDS-port and
   // global -> LDS traffic per FLOP; it needs one tile per CU and a long K loop, and has no LayerNorm / GEGLU / row-sum epilogue.
-  // Measured against the kernel each shape had before (tools/ps_check.py --time, one process, us): dense 32768x640x2560 117 vs
-  // 124, 131072x320x1280 146 vs 158, 32768x640x640 43 vs 52; convolutions at 32x32 latents 640->640 258 vs 290, 1280->640 468
-  // vs 556, 1280->1280 945 vs 963; behind where the 256-row tiles leave CUs idle (M = 8192: 128 tiles, 154 vs 109) and on the
-  // 64x64-latent convolutions (320->320 296 vs 265, 640->640 1016 vs 1007).
+  // Measured against the kernel each shape had before (tools/ps_check.py --time, one process, us): dense 32768x640x2560 106 vs
+  // 124, 131072x320x1280 136 vs 157, 32768x640x640 42 vs 52, 32768x1920x640 (folded LayerNorm) 90 vs 102, GEGLU projections
+  // 32768x5120x640 260 vs 331, 8192x10240x1280 210 vs 291 (1.02 PFLOP/s), 2048x10240x1280 58 vs 77; convolutions at 32x32
+  // latents 640->640 228 vs 290, 1280->640 433 vs 556; behind where the 256-row tiles leave CUs idle (M = 8192 x N = 1280: 128
+  // tiles, 154 vs 109; 8192x3840x1280: 384 tiles = 1.5 rounds, 107 vs 95) and on the 64x64-latent convolutions (320->320 296 vs
+  // 265).  Step, one box, knobs build: off 66.04 / 65.82, convolutions only 65.84 / 65.62, + GEGLU 64.95 / 64.79, + plain dense
+  // 64.37 / 64.34, + folded-LayerNorm projections 63.75 / 63.94.
   // CA_GEMM_PQ (experiment builds): 0 = never, 1 = every launch it can take
   static const int pq_env = CA_KNOB("CA_GEMM_PQ", -1);
   if (allow_pq && pq_env != 0 && pq_capable(p, mode)) {
     const int64_t tiles = (int64_t)ceil_div_i(p.m, 256) * (p.n / 320);
-    const bool dflt = mode == 1 ? (tiles >= 256 && tiles < 512) : (tiles >= 256 && nt >= 8 && !wres_eligible(p));
-    if ((pq_env < 0 && dflt) || pq_env == 1) {
+    // (whole rounds of 256 tiles, or many: 8192x3840x1280 = 384 tiles measured 107 vs 95 us on the 128x128 kernel)
+    const bool dflt = mode == 1 ? (tiles >= 256 && tiles < 512) : (tiles >= 256 && (tiles % 256 == 0 || tiles >= 1024) && nt >= 8 && !wres_eligible(p));
+    // (experiment builds, CA_GEMM_PQ: 2 = convolutions + GEGLU projections, 3 = convolutions only, 4 = 2 + plain dense, 5 = everything the rule allows)
+    const bool epi1 = p.geglu || p.ln_colsum || p.ln_stats;
+    const bool dflt2 = dflt && (mode == 1 || p.geglu), dflt3 = dflt && mode == 1, dflt4 = dflt && (mode == 1 || p.geglu || !epi1);
+    if ((pq_env < 0 && dflt) || pq_env == 1 || (pq_env == 2 && dflt2) || (pq_env == 3 && dflt3) || (pq_env == 4 && dflt4) || (pq_env == 5 && dflt)) {
       g.kind = PK_PQ;
       g.bm = 256, g.bn = 320, g.tiles = (unsigned)tiles;
       return g;
@@ -857,6 +866,18 @@ extern "C" int ca_gemm_ln_inline_supported(const ca_gemm_args* a) {
   GemmKParams p{};
   if (!a || !a->ln_colsum || gemm_fill(a, p) != CA_OK) return 0;
   return wres_eligible(p) ? 1 : 0;
+}
+
+// 1 if this launch, which hands over partial sums (ln_parts > 0), would run on a kernel that takes finished (mean, rstd) only
+// and is the faster one for the shape (the 256 x 320 streaming kernel): the caller then finishes the sums (ca_ln_finish_sums)
+// and passes ln_parts = 0.
+extern "C" int ca_gemm_wants_finished_stats(const ca_gemm_args* a) {
+  GemmKParams p{};
+  if (!a || !a->ln_colsum || !a->ln_stats || a->ln_parts <= 0 || a->row_sums_out) return 0;
+  ca_gemm_args b = *a;
+  b.ln_parts = 0;
+  if (gemm_fill(&b, p) != CA_OK) return 0;
+  return plan_gemm(p, 0).kind == PK_PQ ? 1 : 0;
 }
 
 extern "C" int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* a) {

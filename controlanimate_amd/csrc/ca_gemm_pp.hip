@@ -71,7 +71,7 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
     const unsigned c_bytes = (unsigned)((((int64_t)p.m - 1) * p.ldc + p.n) * 2);
     const unsigned res_bytes = p.res ? (unsigned)((((int64_t)p.m - 1) * p.ld_res + p.n) * 2) : 0u;
     const unsigned grid = tiles < (unsigned)cu_count() ? tiles : (unsigned)cu_count();
-#ifdef CA_EXPERIMENTS
+#ifdef CA_STAMPS
     if (p.dbg == 9) {  // timing experiment: shader-clock stamps of block 0, printed to stderr (first launch only)
       static unsigned long long* dbuf = nullptr;
       if (!dbuf && hipMalloc(&dbuf, 4096 * 8) != hipSuccess) return CA_ERR_LAUNCH;
@@ -99,6 +99,11 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
       return CA_OK;
     }
 #endif
+    if (MODE == 0 && (p.geglu || p.ln_colsum || p.ln_stats)) {
+      const unsigned cb = p.geglu ? (unsigned)((((int64_t)p.m - 1) * p.ldc + p.n / 2) * 2) : c_bytes;
+      hipLaunchKernelGGL((k_gemm_pq<DT, 0, 1>), dim3(grid), dim3(512), 0, st, p, (int)tiles, cb, 0u);
+      return CA_OK;
+    }
     hipLaunchKernelGGL((k_gemm_pq<DT, MODE>), dim3(grid), dim3(512), 0, st, p, (int)tiles, c_bytes, res_bytes);
     return CA_OK;
   }
@@ -107,7 +112,7 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
     const unsigned c_bytes = (unsigned)((((int64_t)p.m - 1) * p.ldc + ncols) * 2);
     const unsigned res_bytes = p.res ? (unsigned)((((int64_t)p.m - 1) * p.ld_res + p.n) * 2) : 0u;
     const unsigned grid = tiles < (unsigned)cu_count() ? tiles : (unsigned)cu_count();
-#ifdef CA_EXPERIMENTS
+#ifdef CA_STAMPS
     if (p.dbg == 9) {  // timing experiment: shader-clock stamps of block 0, printed to stderr (first launch only)
       static unsigned long long* dbuf = nullptr;
       if (!dbuf && hipMalloc(&dbuf, 4096 * 8) != hipSuccess) return CA_ERR_LAUNCH;

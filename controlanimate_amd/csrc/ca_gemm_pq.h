@@ -19,11 +19,13 @@
 //
 // Persistent over tiles, epilogue straight from the accumulators with 16-byte stores (weight rows of MFMA-tile pairs
 // interleaved: ca_ps_col), stores fire-and-forget, both groups' epilogues in the same interval -- all as in ca_gemm_ps.h.
-// Requirements: N % 320 == 0, >= 2 K tiles, fp16 / bf16 output, no GEGLU / LayerNorm fold / row sums / activation / second
-// dense source, 32-bit byte offsets, row-bias groups of a multiple of 128 rows; convolutions: pad 1, no upsampling, < 2^23
+// Requirements: N % 320 == 0, >= 2 K tiles, fp16 / bf16 output, no row sums / activation / second dense source, LayerNorm fold
+// and GEGLU only without a residual (EPI = 1), 32-bit byte offsets, row-bias groups of a multiple of 128 rows; convolutions: pad 1, no upsampling, < 2^23
 // input pixels.
 
-template <int DT, int MODE>
+// EPI = 0: bias, row bias, alpha, residual (GEMM and convolution).  EPI = 1 (dense only): LayerNorm fold with finished (mean,
+// rstd) per row, bias, alpha and optionally GEGLU; no residual, no row bias.
+template <int DT, int MODE, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_total, unsigned c_bytes, unsigned res_bytes) {
   constexpr int BM = 256, BN = 320, KT = 64;
   constexpr int TM = 8, TN = 5;
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
   constexpr int OFF_A = 0, OFF_B0 = A_ROWS * KT, OFF_B1 = (A_ROWS + B0_ROWS) * KT;
   constexpr int BUF = (A_ROWS + B0_ROWS + B1_ROWS) * KT;  // elements of one K tile (72 KB)
   constexpr int PAR_BASE = 2 * BUF * 2;
-  constexpr int P_BI = 0, P_RB0 = 1280, P_RB1 = 2560, PSET = 4096;  // per tile: bias | row bias group 0 | group 1, 320 floats each
+  constexpr int P_BI = 0, P_RB0 = 1280, P_RB1 = 2560, P_CS = 3840, PSET = EPI == 1 ? 5120 : 4096;  // per tile: bias | row bias group 0 | group 1 | column sums, 320 floats each
   constexpr int FLAG_BASE = PAR_BASE + 2 * PSET;  // per wave: 2 flag slots of 256 B (buffer parity)
   constexpr int SMEM_BYTES = FLAG_BASE + 8 * 2 * 256;
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
@@ -59,6 +61,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_bi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.w), 0, p.bias ? (unsigned)p.n * 4u : 0u, 0x00020000);
+  const bool geglu = EPI == 1 && p.geglu != 0;
   const unsigned long long res_addr = (unsigned long long)(p.res ? (const void*)p.res : (const void*)p.c);
   const u32x4 rs_res = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)res_addr), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((res_addr >> 32) & 0xffffu)),
                         (unsigned)__builtin_amdgcn_readfirstlane((int)(p.res ? res_bytes : 0u)), 0x00020000u};
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
                                                                          p.rowbias ? (unsigned)(((int64_t)(rb_groups - 1) * p.ld_rowbias + p.n) * 4) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_seq = __builtin_amdgcn_make_buffer_rsrc((void*)ca_seq_table.v, 0, 4096u, 0x00020000);
 
-#ifdef CA_EXPERIMENTS
+#ifdef CA_STAMPS  // (python -m controlanimate_amd._build --experiments --stamps: the stamp code costs registers -- the 256 x 320 kernel spills with it)
   unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(p.partial);
   int stamp_i = 0;
   auto stamp = [&](int tag) __attribute__((always_inline)) {
@@ -132,18 +135,23 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = wid * 16 + i * 8 + r8;  // B0 local row r: quarter r >> 5, MFMA tile (r >> 4) & 1, fragment row r & 15
-      b0_v[i] = (unsigned)(n0 + (r >> 5) * 80 + ca_ps_col((r >> 4) & 1, r & 15, false)) * wld * 2u + (unsigned)((a_chunk0 ^ (4 * i)) * 16);
+      b0_v[i] = (unsigned)(n0 + (r >> 5) * 80 + ca_ps_col((r >> 4) & 1, r & 15, geglu)) * wld * 2u + (unsigned)((a_chunk0 ^ (4 * i)) * 16);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int r1 = wid * 24 + i * 8 + r8;  // B1 local row r1: quarter r1 / 48, MFMA tile 2 + (r1 % 48) / 16, fragment row r1 & 15
-      b1_v[i] = (unsigned)(n0 + (r1 / 48) * 80 + ca_ps_col(2 + (r1 % 48) / 16, r1 & 15, false)) * wld * 2u + (unsigned)((b1_chunk0 ^ (4 * (i & 1))) * 16);
+      b1_v[i] = (unsigned)(n0 + (r1 / 48) * 80 + ca_ps_col(2 + (r1 % 48) / 16, r1 & 15, geglu)) * wld * 2u + (unsigned)((b1_chunk0 ^ (4 * (i & 1))) * 16);
     }
     d_tap = 0;
     d_c0 = 0;
     // epilogue parameters of this tile -> parameter set (seq & 1): 320 floats = 1 KB + 256 B per operand (an absent operand
     // has a descriptor of size 0: zeros)
     unsigned char* pset = smem_b + PAR_BASE + (seq & 1) * PSET;
+    if (EPI == 1 && wid == 4) {
+      const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ln_colsum ? (const void*)p.ln_colsum : (const void*)p.w), 0, p.ln_colsum ? (unsigned)p.n * 4u : 0u, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cs, (__attribute__((address_space(3))) void*)(pset + P_CS), 16, (unsigned)n0 * 4u + lane_o * 16u, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cs, (__attribute__((address_space(3))) void*)(pset + P_CS + 1024), 4, (unsigned)n0 * 4u + 1024u + lane_o * 4u, 0, 0, 0);
+    }
     if (wid >= 1 && wid <= 3) {
       const bool has1 = p.rowbias && m0 / p.rows_per_group + 1 < (int)rb_groups;
       const unsigned base = wid == 1 ? (unsigned)n0 * 4u
@@ -367,6 +375,82 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (parameter reads retired: the set is re-filled two tiles later)
   };
 
+  // ---- EPI = 1: folded LayerNorm ((mean, rstd) per row, finished by the caller: ca_ln_finish_sums), bias, alpha, optional GEGLU.
+  // The statistics of the lane's eight rows are ordinary loads at the start of the epilogue (16 registers); hipcc awaits them
+  // with vmcnt(0) -- loads and stores share the counter and it treats the mix as unordered -- which also retires the previous
+  // tile's stores and the DMA unit in flight: once per tile, ~1 us.  (A version that read the producer's partial sums with
+  // inline-asm loads pipelined against the stores needed 32 more registers: hipcc spilled the asm's destination registers
+  // right behind the load instruction, i.e. before the data had arrived.)  Rows are processed top to bottom and the accumulators
+  // zeroed AFTER the epilogue, so finished rows free their registers: 160 accumulators + column sums and bias of five MFMA
+  // tiles do not fit otherwise, and a spill anywhere puts the K loop's state into scratch as well.
+  auto epilogue_ln = [&](int seq, int m0, int n0) __attribute__((always_inline)) {
+    const unsigned char* pset = smem_b + PAR_BASE + (seq & 1) * PSET;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int l15 = lane_o & 15, g = lane_o >> 4;
+    float2 st[TM];
+    if (p.ln_stats) {
+      const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc((void*)p.ln_stats, 0, (unsigned)p.m * 8u, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + l15;
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_st, m < p.m ? (unsigned)m * 8u : OOB_V, 0, 0));
+        st[i] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) st[i] = make_float2(0.f, 1.f);  // 1 * (x - 0 * 0) = x: the fold is then an exact no-op
+    }
+    f32x4 cs[TN], bi[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c0 = wc * 80 + (geglu ? (j < 4 ? 16 * g + 4 * j : 64 + 4 * g) : (j < 4 ? 32 * (j >> 1) + 8 * g + 4 * (j & 1) : 64 + 4 * g));
+      cs[j] = *reinterpret_cast<const f32x4*>(pset + P_CS + c0 * 4);
+      bi[j] = *reinterpret_cast<const f32x4*>(pset + P_BI + c0 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + l15;
+      const unsigned ro = (m < p.m && p.dbg != 1) ? (unsigned)m * (unsigned)p.ldc * 2u + (unsigned)(geglu ? (n0 >> 1) + wc * 40 : n0 + wc * 80) * 2u : OOB_V;
+      unsigned w[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = st[i].y * (acc[i][j][r] - st[i].x * cs[j][r]);
+          x = (x + bi[j][r]) + 0.f;  // same association as gemm_epilogue (no row bias here)
+          v[r] = x * p.alpha;
+        }
+        if (geglu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = Elem<DT>::to_f(Elem<DT>::from_f(v[r]));  // (the Linear's output is rounded first)
+          const f32x2 gg = gelu_erf_f2((f32x2){v[1], v[3]});
+          w[j] = pack2<DT>(v[0] * gg[0], v[2] * gg[1]);
+        } else if (j < 4) {
+          const unsigned lo = pack2<DT>(v[0], v[1]), hi = pack2<DT>(v[2], v[3]);
+          if ((j & 1) == 0) {
+            w[0] = lo;
+            w[1] = hi;
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[0], w[1], lo, hi}, rs_c, ro + (unsigned)(32 * (j >> 1) + 8 * g) * 2u, 0, 0);
+          }
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])}, rs_c, ro + (unsigned)(64 + 4 * g) * 2u, 0, 0);
+        }
+      }
+      if (geglu) {
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[0], w[1], w[2], w[3]}, rs_c, ro + (unsigned)(8 * g) * 2u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(w[4], rs_c, ro + (unsigned)(32 + 2 * g) * 2u, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (parameter reads retired: the set is re-filled two tiles later)
+  };
+
   // ---------------------------------------------------------------- run
   // Convolutions: group 1 issues K tile cv + 2 in front of its MFMAs of k half 1 instead of K tile cv + 1 behind its reads of
   // k half 0 (a unit then has three intervals to land instead of two; the gather's issue takes ~1300 cycles against ~500 of a
@@ -428,7 +512,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
     // both groups' epilogues in the same interval (ca_gemm_ps.h): one extra barrier for group 0 before, for group 1 after
     if (wr == 0) __builtin_amdgcn_s_barrier();
     stamp(9);
-    epilogue(seq, m0, n0);
+    if (EPI == 1) epilogue_ln(seq, m0, n0);
+    else epilogue(seq, m0, n0);
     stamp(10);
     if (wr == 1) __builtin_amdgcn_s_barrier();
   }

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ps(GemmKParams p, int tiles_tot
                                                                          p.rowbias ? (unsigned)(((int64_t)(rb_groups - 1) * p.ld_rowbias + p.n) * 4) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_seq = __builtin_amdgcn_make_buffer_rsrc((void*)ca_seq_table.v, 0, 4096u, 0x00020000);
 
-#ifdef CA_EXPERIMENTS
+#ifdef CA_STAMPS  // (python -m controlanimate_amd._build --experiments --stamps: the stamp code costs registers -- the 256 x 320 kernel spills with it)
   // timing experiment (CA_PP_DBG=9): block 0, waves 0 and 4 (one of each group) stamp the shader clock into p.partial
   unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(p.partial);
   int stamp_i = 0;

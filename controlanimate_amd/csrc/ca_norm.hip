@@ -860,3 +860,28 @@ extern "C" int ca_layernorm(const ca_layernorm_args* a, void* stream) {
   CA_CHECK_LAUNCH("ca_layernorm");
   return CA_OK;
 }
+
+// ---- LayerNorm statistics from the partial sums a producing GEMM left (ca_gemm_args.row_sums_out): (mean, rstd) per row.
+// Same arithmetic, in the same order, as the consuming epilogues that finish the sums themselves (ca_gemm_core.h / ca_gemm_ps.h).
+namespace {
+__global__ __launch_bounds__(256) void k_ln_finish_sums(const float* __restrict__ sums, int parts, int64_t rows, float inv_k, float eps, float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float a = 0.f, q = 0.f;
+  for (int i = 0; i < parts; ++i) {
+    const float2 v = *reinterpret_cast<const float2*>(sums + (r * parts + i) * 2);
+    a = a + v.x;
+    q = q + v.y;
+  }
+  const float mean = a * inv_k;
+  *reinterpret_cast<float2*>(out + r * 2) = make_float2(mean, rsqrtf(fmaxf(q * inv_k - mean * mean, 0.f) + eps));
+}
+}  // namespace
+
+extern "C" int ca_ln_finish_sums(const float* sums, int parts, int64_t rows, int k, float eps, float* mean_rstd, void* stream) {
+  CA_REQUIRE(sums && mean_rstd, "ca_ln_finish_sums: null operand");
+  CA_REQUIRE(parts >= 1 && parts <= 64 && rows > 0 && k > 0, "ca_ln_finish_sums: parts=%d rows=%lld k=%d", parts, (long long)rows, k);
+  hipLaunchKernelGGL(k_ln_finish_sums, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sums, parts, rows, 1.f / (float)k, eps, mean_rstd);
+  CA_CHECK_LAUNCH("ca_ln_finish_sums");
+  return CA_OK;
+}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 7
+#define CA_ABI_VERSION 8
 
 /* element types */
 #define CA_BF16 0
@@ -130,6 +130,14 @@ int ca_gemm_row_sums_parts(const ca_gemm_args* args);
 /* 1 if ca_gemm can take these args with ln_stats == NULL (fields other than the pointers' values are what matters;
  * no launch, no device access). */
 int ca_gemm_ln_inline_supported(const ca_gemm_args* args);
+/* ABI v8: 1 if a consumer launch with partial sums (ln_parts > 0) should rather get finished statistics: the kernel the plan
+ * prefers for the shape (256 x 320 tiles) reads (mean, rstd) only.  The caller then runs ca_ln_finish_sums and passes
+ * ln_stats = its output, ln_parts = 0.  No launch, no device access. */
+int ca_gemm_wants_finished_stats(const ca_gemm_args* args);
+/* ABI v8: (mean, rstd = 1 / sqrt(var + eps)) [rows][2] from `sums` [rows][parts][2] = (sum, sum of squares) per row and
+ * 320-column tile as left by a producing GEMM (row_sums_out); k = the row width.  Same arithmetic and order as the consuming
+ * epilogues that finish the sums themselves (reference: nn.LayerNorm statistics, animatediff/models/attention.py:214-237). */
+int ca_ln_finish_sums(const float* sums, int parts, int64_t rows, int k, float eps, float* mean_rstd, void* stream);
 /* ABI v7: the label of the kernel instantiation ca_gemm would launch for these arguments ("wres160", "pp128x320",
  * "ps128x320", "128x128", "128x160", "128x64_db", "128x128_splitk6", "reg_128x64", ...), written NUL-terminated into
  * buf[len].  No launch, no device access: the choice is a pure function of the sizes, strides, flags and which pointers

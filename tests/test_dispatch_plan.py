@@ -81,10 +81,15 @@ GEMMS = [
     ((2048, 1280, 5120, dict(res=True, workspace=True)), "pp128x320_splitk4"),
     ((2048, 1280, 5120, dict(res=True)), "128x64_db"),                # no scratch handed over: unsplit
     ((2048, 3840, 1280, dict(ln="stats")), "pp128x320"),
-    ((2048, 10240, 1280, dict(geglu=1, ln="stats")), "ps128x320"),
+    ((2048, 10240, 1280, dict(geglu=1, ln="stats")), "pq256x320"),
     ((131072, 320, 640, dict(k2=320)), "ps128x320"),                  # shortcut over the skip concat (K = 320 + 320)
     ((32, 1280, 320, dict()), "128x64_db"),                           # time embedding
     ((32768, 640, 640, dict(row_sums=True)), "ps128x320"),            # the 256 x 320 kernel has no row-sum epilogue: the launch keeps the kernel that has
+    # folded LayerNorm with FINISHED statistics (what kernels.gemm hands over after ca_gemm_wants_finished_stats): 256 x 320 tiles
+    ((32768, 5120, 640, dict(geglu=1, ln="stats")), "pq256x320"),
+    ((8192, 10240, 1280, dict(geglu=1, ln="stats")), "pq256x320"),
+    ((32768, 1920, 640, dict(ln="stats")), "pq256x320"),
+    ((8192, 3840, 1280, dict(ln="stats")), "128x128"),                # 384 tiles = 1.5 rounds of 256: stays
     ((8192, 1280, 5120, dict(res=True)), "pp128x320"),                # 128 tiles of 256 x 320 would leave half the CUs idle
 ]
 
@@ -140,3 +145,18 @@ def test_partial_layernorm_sums_never_reach_a_kernel_that_reads_mean_rstd(capi):
                         ln_colsum=FAKE, ln_eps=1e-5, ln_parts=4)
     buf = C.create_string_buffer(64)
     assert lib.ca_gemm_plan_name(C.byref(bad), buf, 64) < 0 and b"ln_parts" in lib.ca_last_error()
+
+
+def test_consumer_of_partial_sums_is_told_when_finished_statistics_are_better(capi):
+    """ABI v8: ca_gemm_wants_finished_stats -- the launches whose preferred kernel (256 x 320 tiles) reads (mean, rstd) only."""
+    lib = capi.lib()
+
+    def wants(m, n, k, parts, geglu=0):
+        a = capi.GemmArgs(a=FAKE, w=FAKE, c=FAKE, m=m, n=n, k1=k, lda=k, ldc=n // 2 if geglu else n, alpha=1.0, post_scale=1.0, dtype=capi.CA_F16,
+                          geglu=geglu, rows_per_group=1, ln_colsum=FAKE, ln_stats=FAKE, ln_eps=1e-5, ln_parts=parts)
+        return lib.ca_gemm_wants_finished_stats(C.byref(a))
+
+    assert wants(32768, 5120, 640, 2, geglu=1) == 1 and wants(8192, 10240, 1280, 4, geglu=1) == 1 and wants(32768, 1920, 640, 2) == 1
+    assert wants(8192, 3840, 1280, 4) == 0          # keeps the 128 x 128 kernel, which finishes the sums itself
+    assert wants(32768, 1920, 640, 0) == 0          # already finished
+    assert wants(131072, 960, 320, 1) == 0          # K = 320: weight-resident / streaming kernels

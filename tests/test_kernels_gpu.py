@@ -618,6 +618,18 @@ def test_gemm_and_conv_256x320_streaming_kernel(dtype):
         if (ho * ho) % 128 == 0:  # (row-bias groups = images; the kernel takes multiples of 128 rows)
             full.update(rowbias=rn(img, co), rows_per_group=ho * ho)
         cases.append(("conv", f"conv+bias+rowbias+res {img}x{h} {ci}+{c2}->{co} s{stride}", full))
+    # folded LayerNorm (+ GEGLU): finished statistics, and the producer's partial sums (finished by ca_ln_finish_sums, ABI v8)
+    for (m, n, kk, geglu) in [(32768 - 24, 1920, 640, False), (8192, 10240, 1280, True), (2048, 10240, 1280, True)]:
+        a, w = (rn(m, kk) * 1.3 + 0.4).to(dtype), rn(n, kk, scale=kk ** -0.5).to(dtype)
+        bias = rn(n)
+        st = torch.stack([a.float().mean(1), (a.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+        cs = w.float().sum(1).contiguous()
+        cases.append(("gemm", f"LN (mean, rstd){' geglu' if geglu else ''} {m}x{n}x{kk}", dict(a=a, w=w, bias=bias, geglu=geglu, ln=(st, cs), _ln_ref=st)))
+        parts = kk // 320
+        af = a.float().reshape(m, parts, 320)
+        sums = torch.stack([af.sum(2), (af * af).sum(2)], 2).contiguous()
+        cases.append(("gemm", f"LN {parts} partial sums{' geglu' if geglu else ''} {m}x{n}x{kk}",
+                      dict(a=a, w=w, bias=bias, geglu=geglu, ln=(k.RowStats(a, 1e-5, (sums, parts)), cs), _ln_ref=st)))
     for kind, name, kw in cases:
         k._plan_sink = labels = []
         if kind == "conv":
@@ -626,7 +638,7 @@ def test_gemm_and_conv_256x320_streaming_kernel(dtype):
             outs = [k.conv3x3(x, w, **call).clone() for _ in range(2)]
             ref = ps_check.conv_reference(kw)
         else:
-            outs = [k.gemm(**kw).clone() for _ in range(2)]
+            outs = [k.gemm(**{a_: b_ for a_, b_ in kw.items() if not a_.startswith("_")}).clone() for _ in range(2)]
             ref = ps_check.gemm_reference(kw)
         k._plan_sink = None
         assert set(labels) == {"pq256x320"}, (name, labels)
