@@ -567,7 +567,8 @@ inline GemmPlan plan_gemm(const GemmKParams& p, int mode, bool allow_pq = true) 
   if (allow_pq && pq_env != 0 && pq_capable(p, mode)) {
     const int64_t tiles = (int64_t)ceil_div_i(p.m, 256) * (p.n / 320);
     // (whole rounds of 256 tiles, or many: 8192x3840x1280 = 384 tiles measured 107 vs 95 us on the 128x128 kernel)
-    const bool dflt = mode == 1 ? (tiles >= 256 && tiles < 512) : (tiles >= 256 && (tiles % 256 == 0 || tiles >= 1024) && nt >= 8 && !wres_eligible(p));
+    // (convolutions, clean build: 64x64 latents 640->320 468 vs 508, 640->640 908 vs 986, 32x32 1280->1280 820 vs 929; 320->320 at 64x64 -- N = 320, 45 K tiles -- 256 vs 251: not)
+    const bool dflt = mode == 1 ? (tiles >= 256 && (p.n >= 640 || nt >= 64)) : (tiles >= 256 && (tiles % 256 == 0 || tiles >= 1024) && nt >= 8 && !wres_eligible(p));
     // (experiment builds, CA_GEMM_PQ: 2 = convolutions + GEGLU projections, 3 = convolutions only, 4 = 2 + plain dense, 5 = everything the rule allows)
     const bool epi1 = p.geglu || p.ln_colsum || p.ln_stats;
     const bool dflt2 = dflt && (mode == 1 || p.geglu), dflt3 = dflt && mode == 1, dflt4 = dflt && (mode == 1 || p.geglu || !epi1);

@@ -101,11 +101,11 @@ CONVS = [
     ((32, 8, 1280, 1280, dict()), "128x128_splitk6"),
     ((32, 8, 1280, 1280, dict(workspace=False)), "128x64_db"),
     ((32, 16, 2560, 1280, dict(cin2=1280)), "pp128x320"),
-    ((32, 64, 640, 320, dict(cin2=320)), "128x160"),
-    ((32, 64, 640, 640, dict(upsample=0)), "128x128"),
-    ((32, 32, 1280, 1280, dict()), "128x128"),
+    ((32, 64, 640, 320, dict(cin2=320)), "pq256x320"),
+    ((32, 64, 640, 640, dict(upsample=0)), "pq256x320"),
+    ((32, 32, 1280, 1280, dict()), "pq256x320"),
     ((32, 32, 1920, 640, dict(cin2=640)), "pq256x320"),
-    ((32, 64, 960, 320, dict(cin2=320)), "128x160"),
+    ((32, 64, 960, 320, dict(cin2=320)), "pq256x320"),
     ((32, 64, 320, 320, dict(stride=2)), "pp128x320"),                # Downsample: 32x32 outputs
     ((32, 16, 1280, 1280, dict(upsample=1)), "128x128"),              # Upsample: 32x32 outputs
     ((32, 64, 8, 320, dict()), "reg_128x64"),                         # conv_in (4 latent channels padded to 8)
