@@ -1,4 +1,5 @@
-"""s_memtime stamps of one block of the 256 x 320 streaming kernel (experiments library, CA_PP_DBG=9, CA_GEMM_PQ=1):
+"""s_memtime stamps of one block of the 256 x 320 streaming kernel (stamps library: python -m controlanimate_amd._build --experiments --stamps;
+CA_HIP_LIB=controlanimate_amd/csrc/libcontrolanimate_hip_stamps.so CA_PP_DBG=9 CA_GEMM_PQ=1; the stamp code costs registers: the kernel spills with it):
     python tools/pq_stamps.py conv IMAGES H CIN COUT | gemm M N K [res]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

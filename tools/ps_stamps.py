@@ -1,4 +1,5 @@
-"""s_memtime stamps of one block of the persistent streaming kernel (experiments library, CA_PP_DBG=9, CA_GEMM_PS=1):
+"""s_memtime stamps of one block of the persistent streaming kernel (stamps library: python -m controlanimate_amd._build --experiments --stamps;
+CA_HIP_LIB=controlanimate_amd/csrc/libcontrolanimate_hip_stamps.so CA_PP_DBG=9 CA_GEMM_PS=1):
     python tools/ps_stamps.py M N K [geglu|res]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
