@@ -509,7 +509,7 @@ inline bool pq_capable(const GemmKParams& p, int mode) {
   const bool conv_ok = mode != 1 || (p.pad_lo == 1 && p.ups == 0 && p.hin >= 2 && p.win >= 2 && (int64_t)(p.m / (p.hout * p.wout) + 1) * p.hin * p.win < (1 << 23) &&
                                      (p.hout - 1) * p.stride < p.hin && (p.wout - 1) * p.stride < p.win);
   const bool epi1 = p.geglu || p.ln_colsum || p.ln_stats;  // the LayerNorm / GEGLU epilogue variant: dense, no residual
-  return ps_capable(p) && !p.row_sums && (mode == 1 || p.c2 == 0) && (!p.rowbias || p.rows_per_group % 128 == 0) && conv_ok &&
+  return ps_capable(p) && (!p.row_sums || (mode == 0 && !epi1)) && (mode == 1 || p.c2 == 0) && (!p.rowbias || p.rows_per_group % 128 == 0) && conv_ok &&
          (!epi1 || (mode == 0 && !p.res && !p.rowbias && p.ln_parts == 0 && (!p.ln_colsum || p.ln_stats)));
 }
 
@@ -671,11 +671,15 @@ inline GemmPlan plan_gemm(const GemmKParams& p, int mode, bool allow_pq = true) 
 
 // can the epilogue of this (dense) launch leave per-row sums of its output (ca_gemm_args.row_sums_out)?  Only the 128 x 320
 // tile kernels do; the answer is about the launch the arguments get WITHOUT the pointer.
-inline bool row_sums_capable(GemmKParams p) {
+inline int row_sums_parts_of(GemmKParams p) {  // partial sums per row the launch can leave (0: none)
   p.row_sums = nullptr;
-  const int k = plan_gemm(p, 0, /*allow_pq=*/false).kind;  // (the 256 x 320 kernel cannot; with the pointer set the plan skips it)
-  return (k == PK_PP2 || k == PK_PS) && !p.geglu && !p.out_f32;
+  if (p.geglu || p.out_f32) return 0;
+  const int k = plan_gemm(p, 0).kind;
+  if (k == PK_PP2 || k == PK_PS) return p.n / 320;          // one (sum, sum of squares) per 320-column tile
+  if (k == PK_PQ && !p.ln_colsum && !p.ln_stats) return 4 * (p.n / 320);  // the 256 x 320 kernel: one per 80-column wave quarter
+  return 0;
 }
+inline bool row_sums_capable(const GemmKParams& p) { return row_sums_parts_of(p) > 0; }
 
 inline void plan_label(const GemmPlan& g, char* buf, int len) {
   switch (g.kind) {
@@ -860,7 +864,7 @@ extern "C" int ca_gemm_row_sums_parts(const ca_gemm_args* a) {
   const int kc = a->k1 + a->k2;
   const bool dma_ok = kc % BK == 0 && (a->k2 == 0 || a->k1 % BK == 0);
   if (dma_ok && !p.ln_inline && !p.ln_parts && a->workspace && splitk_plan_dense(p.m, p.n, p.kc_tiles, p.geglu, p.out_f32) > 1) return 0;
-  return row_sums_capable(p) ? p.n / 320 : 0;
+  return row_sums_parts_of(p);
 }
 
 extern "C" int ca_gemm_ln_inline_supported(const ca_gemm_args* a) {

@@ -104,6 +104,10 @@ int launch_pp(const GemmKParams& p, int bn, unsigned tiles, hipStream_t st) {
       hipLaunchKernelGGL((k_gemm_pq<DT, 0, 1>), dim3(grid), dim3(512), 0, st, p, (int)tiles, cb, 0u);
       return CA_OK;
     }
+    if (MODE == 0 && p.row_sums) {
+      hipLaunchKernelGGL((k_gemm_pq<DT, 0, 2>), dim3(grid), dim3(512), 0, st, p, (int)tiles, c_bytes, res_bytes);
+      return CA_OK;
+    }
     hipLaunchKernelGGL((k_gemm_pq<DT, MODE>), dim3(grid), dim3(512), 0, st, p, (int)tiles, c_bytes, res_bytes);
     return CA_OK;
   }

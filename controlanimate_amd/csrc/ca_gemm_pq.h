@@ -24,7 +24,8 @@
 // input pixels.
 
 // EPI = 0: bias, row bias, alpha, residual (GEMM and convolution).  EPI = 1 (dense only): LayerNorm fold with finished (mean,
-// rstd) per row, bias, alpha and optionally GEGLU; no residual, no row bias.
+// rstd) per row, bias, alpha and optionally GEGLU; no residual, no row bias.  EPI = 2 (dense only): EPI = 0 + row sums of the
+// stored output for the next LayerNorm (ca_gemm_args.row_sums_out), one partial sum per 80-column wave quarter.
 template <int DT, int MODE, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_total, unsigned c_bytes, unsigned res_bytes) {
   constexpr int BM = 256, BN = 320, KT = 64;
@@ -327,6 +328,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
                    : "v"(o0), "v"(o1), "v"(o2), "s"(rs_res)
                    : "memory");
     };
+    float rsum[TM], rsq[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rsum[i] = rsq[i] = 0.f;
     if (p.res) res_load(0, 0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -368,8 +372,33 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
                              Elem<DT>::to_f((u16)(w[k] >> 16)) + Elem<DT>::to_f((u16)(rr >> 16)));
           }
         }
+        if (EPI == 2) {  // row sums: of the values as stored (rounded)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (k >= 2 * nq) break;
+            const float lo = Elem<DT>::to_f((u16)(w[k] & 0xffffu)), hi = Elem<DT>::to_f((u16)(w[k] >> 16));
+            rsum[i] += lo + hi;
+            rsq[i] = fmaf(lo, lo, fmaf(hi, hi, rsq[i]));
+          }
+        }
         if (pr < 2) __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[0], w[1], w[2], w[3]}, rs_c, ro + (unsigned)(32 * pr + 8 * g) * 2u, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b64((u32x2){w[0], w[1]}, rs_c, ro + (unsigned)(64 + 4 * g) * 2u, 0, 0);
+      }
+    }
+    if (EPI == 2) {
+      // ca_gemm_args.row_sums_out: (sum, sum of squares) of the wave's 80 stored columns per row -- one partial sum per wave
+      // quarter, [M][4 * N / 320][2]; the consumer finishes them with ca_ln_finish_sums.  Lanes l, l^16, l^32, l^48 hold pieces
+      // of one row; written after the last residual load has been awaited (the counted waits above count no other stores).
+      const int tn4 = (n0 / BN) * 4 + wc, parts = (p.n / BN) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float a = rsum[i], b = rsq[i];
+        a += __shfl_xor(a, 16);
+        b += __shfl_xor(b, 16);
+        a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 32);
+        const int m = m0 + wr * 128 + i * 16 + l15;
+        if (g == 0 && m < p.m) *reinterpret_cast<float2*>(p.row_sums + ((int64_t)m * parts + tn4) * 2) = make_float2(a, b);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (parameter reads retired: the set is re-filled two tiles later)
@@ -513,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
     if (wr == 0) __builtin_amdgcn_s_barrier();
     stamp(9);
     if (EPI == 1) epilogue_ln(seq, m0, n0);
-    else epilogue(seq, m0, n0);
+    else epilogue(seq, m0, n0);  // (EPI = 0 / 2)
     stamp(10);
     if (wr == 1) __builtin_amdgcn_s_barrier();
   }

@@ -96,8 +96,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
             elif st.sums is not None:
                 rs, parts = st.sums
                 assert rs.shape == (m, parts, 2) and rs.dtype == torch.float32 and rs.is_contiguous()
-                args.ln_stats, args.ln_parts = _p(rs), parts
-                if lib().ca_gemm_wants_finished_stats(C.byref(args)):
+                args.ln_stats, args.ln_parts = _p(rs), min(parts, 4)
+                # (more than 4 partial sums per row -- a producer on the 256 x 320 kernel leaves one per 80-column wave quarter --
+                #  are always finished first: the consuming epilogues add at most 4)
+                if parts > 4 or lib().ca_gemm_wants_finished_stats(C.byref(args)):
                     # the kernel the plan prefers for this shape (256 x 320 tiles) reads finished (mean, rstd): a 3 us pass
                     # over [m, parts, 2] instead of the consumer's epilogue adding the parts (ABI v8)
                     fin = getattr(st, "_finished", None)

@@ -125,7 +125,9 @@ typedef struct ca_gemm_args {
 int ca_gemm(const ca_gemm_args* args, void* stream);
 /* bytes of split-K scratch this launch can use (0: it would not split) */
 int64_t ca_gemm_workspace_bytes(const ca_gemm_args* args);
-/* partial sums per row this launch can leave in row_sums_out (0: it cannot) */
+/* partial sums per row this launch can leave in row_sums_out (0: it cannot).  N / 320 on the 128 x 320-tile kernels; ABI v8:
+ * 4 * N / 320 on the 256 x 320 kernel (one per 80-column wave quarter) -- a consumer's ln_parts takes at most 4, so more are
+ * finished with ca_ln_finish_sums first. */
 int ca_gemm_row_sums_parts(const ca_gemm_args* args);
 /* 1 if ca_gemm can take these args with ln_stats == NULL (fields other than the pointers' values are what matters;
  * no launch, no device access). */

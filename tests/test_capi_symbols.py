@@ -95,7 +95,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu(capi):
     def plain(m, n, k, **kw):
         return capi.GemmArgs(a=fake, w=fake, c=fake, m=m, n=n, k1=k, lda=k, ldc=n, dtype=1, alpha=1.0, post_scale=1.0, **kw)
     assert lib.ca_gemm_row_sums_parts(C.byref(plain(8192, 1280, 1280))) == 4        # 256 tiles of 128x320
-    assert lib.ca_gemm_row_sums_parts(C.byref(plain(32768, 640, 640))) == 2
+    assert lib.ca_gemm_row_sums_parts(C.byref(plain(32768, 640, 640))) == 8          # ABI v8: the 256x320 kernel, one per 80-column wave quarter
     assert lib.ca_gemm_row_sums_parts(C.byref(plain(2048, 1280, 1280))) == 0        # 64 tiles: another kernel takes it
     assert lib.ca_gemm_row_sums_parts(C.byref(plain(131072, 320, 320))) == 0        # the weight-resident kernel takes it
     assert lib.ca_gemm_row_sums_parts(C.byref(plain(8192, 1280, 1280, geglu=1))) == 0

@@ -68,7 +68,7 @@ GEMMS = [
     ((131072, 320, 320, dict()), "wres160"),                          # proj_in, to_q (cross)
     ((131072, 960, 320, dict(ln="inline")), "wres160"),               # q|k|v
     ((32768, 5120, 640, dict(geglu=1, ln=2)), "ps128x320"),
-    ((32768, 640, 640, dict(res=True, row_sums=True)), "ps128x320"),
+    ((32768, 640, 640, dict(res=True, row_sums=True)), "pq256x320"),    # (ABI v8: row sums per wave quarter, finished by ca_ln_finish_sums)
     ((32768, 640, 640, dict()), "pq256x320"),
     ((32768, 1920, 640, dict(ln=2)), "128x128"),
     ((8192, 10240, 1280, dict(geglu=1, ln=4)), "ps128x320"),
@@ -84,7 +84,7 @@ GEMMS = [
     ((2048, 10240, 1280, dict(geglu=1, ln="stats")), "pq256x320"),
     ((131072, 320, 640, dict(k2=320)), "ps128x320"),                  # shortcut over the skip concat (K = 320 + 320)
     ((32, 1280, 320, dict()), "128x64_db"),                           # time embedding
-    ((32768, 640, 640, dict(row_sums=True)), "ps128x320"),            # the 256 x 320 kernel has no row-sum epilogue: the launch keeps the kernel that has
+    ((32768, 640, 640, dict(row_sums=True)), "pq256x320"),
     # folded LayerNorm with FINISHED statistics (what kernels.gemm hands over after ca_gemm_wants_finished_stats): 256 x 320 tiles
     ((32768, 5120, 640, dict(geglu=1, ln="stats")), "pq256x320"),
     ((8192, 10240, 1280, dict(geglu=1, ln="stats")), "pq256x320"),

@@ -566,8 +566,9 @@ def test_layernorm_statistics_handed_from_producer_to_consumer(m, c, dtype):
     sums = k.row_sums_of(x)
     assert sums is not None, "the 128x320-tile kernel takes this shape: row sums expected"
     rs, parts = sums
-    assert parts == c // 320 and rs.shape == (m, parts, 2)
-    xf = x.float().view(m, parts, 320)
+    # one partial sum per 320-column tile (128x320-tile kernels) or per 80-column wave quarter (256x320 kernel, ABI v8)
+    assert parts in (c // 320, 4 * (c // 320)) and rs.shape == (m, parts, 2)
+    xf = x.float().view(m, parts, c // parts)
     assert torch.allclose(rs[..., 0], xf.sum(-1), rtol=1e-4, atol=2e-2) and torch.allclose(rs[..., 1], (xf * xf).sum(-1), rtol=1e-4, atol=2e-2)
     n = 3 * c
     w2 = rnd(n, c, dtype=torch.float32, scale=c ** -0.5, seed=74).to(dtype).to(DEV)
