@@ -169,6 +169,8 @@ def rocprof_kernel_name(family: str, dtype: str) -> str:
         return f"k_gemm_pp2<{dt}, {mode}"
     if tile == "ps128x320":
         return f"k_gemm_ps<{dt}, {mode}"
+    if tile.startswith("pq256x320"):  # (every epilogue variant of the family: k_gemm_pq<dt, mode, EPI>)
+        return f"k_gemm_pq<{dt}, {mode}"
     base = tile.split("_")[0]
     bm, bn = base.split("x")
     waves = "4, 1" if base == "128x64" else "2, 2"
@@ -184,6 +186,8 @@ def kernel_display_name(family: str) -> str:
         return f"k_gemm_pp2<{family}>"
     if tile == "ps128x320":
         return f"k_gemm_ps<{family}>"
+    if tile.startswith("pq256x320"):
+        return f"k_gemm_pq<{family}>"
     return f"k_gemm_dma<{family}>"
 
 
@@ -208,9 +212,11 @@ def pmc_traffic(kernel_prefix: str, workload_key: str, dtype: str):
         meta = doc.get("workload", {"key": "config2", "dtype": "fp16"})  # (round 1 summary: config 2, fp16)
         if meta.get("key") != workload_key or meta.get("dtype") != dtype:
             continue
-        for name, row in doc["kernels"].items():
-            if name.startswith(kernel_prefix):
-                return row["hbm_bytes_per_launch"], fn
+        # (a family can be several template instantiations -- the epilogue variants of k_gemm_pq: launch-weighted mean)
+        rows = [row for name, row in doc["kernels"].items() if name.startswith(kernel_prefix)]
+        n = sum(r.get("launches", 1) for r in rows)
+        if rows and n > 0:
+            return int(sum(r["hbm_bytes_per_launch"] * r.get("launches", 1) for r in rows) / n), fn
     return None, None
 
 
