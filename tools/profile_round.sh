@@ -23,7 +23,7 @@ F=$(find "$OUT/fetch" -name "*counter_collection.csv" | head -1); W=$(find "$OUT
 [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_traffic_json.py "$F" "$W" config2 fp16 > profiles/${TAG}_pmc_traffic.json
 Q=$(find "$OUT/sq" -name "*counter_collection.csv" | head -1); [ -n "$Q" ] && python3 tools/pmc_sq_summary.py "$Q" > profiles/${TAG}_pmc_sq_summary.txt
 M=$(find "$OUT/mfma" -name "*counter_collection.csv" | head -1); [ -n "$M" ] && python3 tools/pmc_mfma_summary.py "$M" > profiles/${TAG}_mfma_util.txt
-cp profiles/${TAG}_* gpurun_out/ 2>/dev/null
+for f in bench_kernel_stats.csv bench_kernel_stats_run.json bench_kernel_stats_single_stream.csv pmc_traffic.json pmc_sq_summary.txt mfma_util.txt; do cp profiles/${TAG}_$f gpurun_out/ 2>/dev/null; done  # (only what this script wrote)
 ls -la profiles/${TAG}_*
 # the raw traces stay on the box: gpurun merges at most 64 MiB back
 rm -rf "$OUT/trace" "$OUT/trace1s" "$OUT/fetch" "$OUT/write" "$OUT/sq" "$OUT/mfma"
