@@ -112,6 +112,7 @@ SYMBOLS = {
     "ca_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "ca_attention": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "ca_add_bcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "ca_repeat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "ca_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ca_timestep_embedding": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ca_latents_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -172,7 +172,7 @@ class Transformer3DModel(nn.Module):
         y = K.carry_row_sums(y0.view(images, h * w, -1), y0)
         if shared_half:
             y = self.transformer_blocks[0].forward_self(y)
-            y, x = torch.cat([y, y]), torch.cat([x, x])
+            y, x = K.repeat_batch(y), K.repeat_batch(x)  # (= torch.cat([t, t]), one read each)
             images, rows = 2 * images, 2 * rows
             y = self.transformer_blocks[0].forward_rest(y, ctx)
         for blk in (self.transformer_blocks[1:] if shared_half else self.transformer_blocks):

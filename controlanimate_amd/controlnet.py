@@ -138,7 +138,7 @@ class ControlNetModel(HipModelMixin, nn.Module):
         if doubled:
             cond = cond[: cond.shape[0] // 2]
         emb = ce(K.ncfhw_to_nhwc(cond.to(device).unsqueeze(2), ce.conv_in.cin_pad, self.act_dtype))
-        return torch.cat([emb, emb]) if doubled else emb
+        return K.repeat_batch(emb) if doubled else emb
 
     def refresh_window_caches(self) -> int:
         """HipModelMixin.refresh_window_caches + the hint embedding of the current control images (in place)."""
@@ -184,7 +184,7 @@ class ControlNetModel(HipModelMixin, nn.Module):
         if shared:
             half = images // 2
             xh = self.conv_in.run(x[:half], residual=hint[:half])
-            outs = [torch.cat([xh, xh])]
+            outs = [K.repeat_batch(xh)]  # (= torch.cat([xh, xh]), one read)
             x, o = first(xh, ctx, half_ctx=dataclasses.replace(ctx, b=half))
             outs += o
         else:

@@ -176,6 +176,26 @@ extern "C" int ca_add_bcast(const void* a, const void* b, void* out, int64_t n, 
   return CA_OK;
 }
 
+// `times` copies of a buffer behind each other: torch.cat([x] * times) along the leading dimension with ONE read of x
+// (the two CFG halves of the shared prefix, DESIGN.md section 3: the reference's torch.cat([latents] * 2) made them identical)
+namespace {
+__global__ __launch_bounds__(256) void k_repeat(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t n16, int times) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    const u32x4 v = src[i];
+    for (int t = 0; t < times; ++t) dst[(int64_t)t * n16 + i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int ca_repeat(const void* src, void* dst, int64_t bytes, int32_t times, void* stream) {
+  CA_REQUIRE(src && dst, "ca_repeat: null operand");
+  CA_REQUIRE(bytes > 0 && bytes % 16 == 0 && times >= 1 && times <= 64, "ca_repeat: bytes=%lld (multiple of 16) times=%d", (long long)bytes, times);
+  CA_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "ca_repeat: operands must be 16-byte aligned");
+  hipLaunchKernelGGL(k_repeat, dim3(blocks_for(bytes / 16, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, bytes / 16, times);
+  CA_CHECK_LAUNCH("ca_repeat");
+  return CA_OK;
+}
+
 // Row softmax of an fp32 score matrix into the activation dtype: the VAE's single-head, head_dim 512
 // attention (diffusers AutoencoderKL mid block) runs as GEMM (scores, fp32) -> this -> GEMM (P V);
 // one block per row, three passes over a row that stays in L2.

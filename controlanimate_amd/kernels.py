@@ -336,6 +336,20 @@ def add_bcast(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = No
     return out
 
 
+_REPEAT_ON = os.environ.get("CA_REPEAT_KERNEL", "1") != "0"
+
+
+def repeat_batch(x: torch.Tensor, times: int = 2) -> torch.Tensor:
+    """torch.cat([x] * times) along dim 0 with one read of x (ca_repeat, ABI v8; CA_REPEAT_KERNEL=0: torch.cat, for A/B runs)."""
+    if not _REPEAT_ON:
+        return torch.cat([x] * times)
+    _req_cuda(x)
+    assert x.is_contiguous() and (x.numel() * x.element_size()) % 16 == 0
+    out = torch.empty((times * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+    check(lib().ca_repeat(x.data_ptr(), out.data_ptr(), x.numel() * x.element_size(), times, _stream()), "ca_repeat")
+    return out
+
+
 def softmax_rows(x: torch.Tensor, dtype: torch.dtype, scale: float = 1.0) -> torch.Tensor:
     """Row softmax of an fp32 [rows, cols] score matrix (last dim contiguous), output in `dtype`."""
     _req_cuda(x)

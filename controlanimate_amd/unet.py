@@ -400,7 +400,7 @@ class UNet3DConditionModel(HipModelMixin, nn.Module):
         if shared:
             half_ctx = dataclasses.replace(ctx, b=1, temb=temb[:1], emb_groups=1)
             xh = self.conv_in.run(x[: x.shape[0] // 2])
-            skips = [torch.cat([xh, xh])]
+            skips = [K.repeat_batch(xh)]  # (= torch.cat([xh, xh]), one read)
             x, outs = first(xh, ctx, half_ctx=half_ctx)
             skips += outs
         else:

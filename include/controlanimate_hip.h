@@ -309,6 +309,10 @@ int ca_attention(const ca_attn_args* args, void* stream);
  * b=1 residuals over the CFG batch (animatediff/models/unet.py:567-576,584-585). n multiple of 8. */
 int ca_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t b_period,
                  int32_t dtype, void* stream);
+/* ABI v8: dst = `times` copies of the `bytes` of src behind each other (one read of src): torch.cat([x] * times) along the
+ * leading dimension -- the reference's torch.cat([latents] * 2) (animatediff/pipelines/controlanimation_pipeline.py:797) makes
+ * the two CFG halves identical, the shared prefix is computed once and repeated here.  bytes % 16 == 0, 16-byte aligned. */
+int ca_repeat(const void* src, void* dst, int64_t bytes, int32_t times, void* stream);
 
 /* y[r, :] = softmax(scale * x[r, :]) for an fp32 score matrix, written in `dtype`.
  * Replaces the softmax inside F.scaled_dot_product_attention for the VAE's mid-block attention

@@ -459,6 +459,15 @@ def test_add_bcast():
     close(out, a.float() + b.float(), torch.bfloat16, "add_bcast")
 
 
+def test_repeat_batch_equals_torch_cat():
+    """ca_repeat (ABI v8): the CFG halves of the shared prefix, torch.cat([x, x]) with one read."""
+    k = _k()
+    for shape, dt in (((16, 64, 64, 320), torch.float16), ((3, 7, 8), torch.bfloat16), ((5, 4), torch.float32)):
+        x = rnd(*shape, dtype=dt, seed=3).to(DEV)
+        for times in (2, 3):
+            assert torch.equal(k.repeat_batch(x, times), torch.cat([x] * times))
+
+
 def test_silu_and_timestep_embedding():
     k = _k()
     x = rnd(2, 1280, dtype=torch.float32, seed=53)
