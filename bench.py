@@ -617,7 +617,10 @@ def main():
     torch.cuda.synchronize()
     replays_before = state.get("replays", 0)
     t0 = time.perf_counter()
+    c0 = time.process_time()
     run_k_steps(args.steps, record_events=True)
+    host_enqueue = time.perf_counter() - t0  # the calls have returned, the GPU is still working
+    host_cpu = time.process_time() - c0      # CPU time of the process (all threads) over the same calls
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -688,6 +691,12 @@ def main():
                                             "uploaded, at every window start; the timed region begins at a window start" if use_graph else
                                             "eager run: nothing is cached outside the timed region except across the steps of a window"),
         "graph_replays_in_timed_region": int(replays_timed) if use_graph else 0,
+        # host side of the product loop per step.  `host_cpu_ms_per_step` = CPU time of the process (all threads) while the K calls
+        # ran: what N ranks on one host compete for.  `host_enqueue_ms_per_step` = wall time until the calls returned, before the
+        # device synchronise: a replay of the captured graph waits for the previous replay of the same graph (measured: 2.3 ms on
+        # an idle queue, ~12 ms behind a running step), so this is mostly waiting, not work
+        "host_cpu_ms_per_step": round(1e3 * host_cpu / args.steps, 3),
+        "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
         "step_algorithmic_tflop": round(step_tflop, 2),
         # utilisation of the dense MFMA peak by the work that was EXECUTED (the shared CFG prefix runs once: see below);
         # `step_mfma_frac_algorithmic` divides the reference's count (both halves) by the same time and overstates it
