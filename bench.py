@@ -493,6 +493,44 @@ def plumbing_only(args):
         torch.distributed.destroy_process_group()
 
 
+
+def matrix_rate_vs_operand_data(dtype):
+    """What the matrix pipes of THIS box sustain on real data (reported beside `roofline`, never part of `value`).
+
+    MI355X clocks and issues to its power budget: the same GEMM binary runs ~1.5x faster on zero-filled operands than on
+    N(0,1) data (DESIGN.md section 3, round-3 findings).  The guide's 2.5 PFLOP/s dense peak is therefore not reachable on the
+    activations this workload multiplies; the rates below say what is: the vendor library's best case (`torch.matmul`, hipBLASLt,
+    8192^3 -- a measurement reference only, the product never calls it) and this package's 256 x 320 kernel on one of the
+    step's own shapes, each on N(0,1) and on zero-filled operands.
+    """
+    from controlanimate_amd import kernels as K
+
+    def rate(fn, flop, it=20):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(it):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(flop * it / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+
+    res = {"unit": "TFLOP/s", "dtype": str(dtype).replace("torch.", "")}
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for name, (m, n, k), ours in (("vendor_gemm_8192x8192x8192", (8192, 8192, 8192), False), ("pq256x320_32768x640x2560", (32768, 640, 2560), True)):
+        a = torch.randn(m, k, device="cuda", generator=g).to(dtype)
+        w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(dtype)
+        fn = (lambda: K.gemm(a, w)) if ours else (lambda: torch.matmul(a, w.t()))
+        r = rate(fn, 2.0 * m * n * k)
+        a.zero_()
+        w.zero_()
+        z = rate(fn, 2.0 * m * n * k)
+        res[name] = {"normal_data": r, "zero_data": z}
+        del a, w
+    return res
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -749,6 +787,8 @@ def main():
                                         "algorithmic_gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0,
                                         "rocprof_name": rocprof_kernel_name(k, args.dtype) or None,
                                         "time_share": round(v["ms"] * 1e-3 / roof_elapsed, 4)} for k, v in sorted(agg.items())}
+    if not args.no_roofline and world == 1 and "roofline" in out:
+        out["roofline"]["matrix_rate_vs_operand_data"] = matrix_rate_vs_operand_data(dtype)
     if args.shapes and rank == 0 and not args.no_roofline:
         for row in timer.by_shape():
             print(row, file=sys.stderr)

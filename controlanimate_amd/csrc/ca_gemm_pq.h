@@ -23,6 +23,14 @@
 // and GEGLU only without a residual (EPI = 1), 32-bit byte offsets, row-bias groups of a multiple of 128 rows; convolutions: pad 1, no upsampling, < 2^23
 // input pixels.
 
+// Timing-only ablations (never in a shipped library: results are wrong): -DCA_PQ_ABLATE=bits, 1 = no global -> LDS units after
+// a block's first two, 2 = no fragment reads, 4 = no MFMAs, 8 = no barriers inside the K loop.
+#ifdef CA_PQ_ABLATE
+#define CA_PQ_ABL(bit) (((CA_PQ_ABLATE) & (bit)) != 0)
+#else
+#define CA_PQ_ABL(bit) false
+#endif
+
 // EPI = 0: bias, row bias, alpha, residual (GEMM and convolution).  EPI = 1 (dense only): LayerNorm fold with finished (mean,
 // rstd) per row, bias, alpha and optionally GEGLU; no residual, no row bias.  EPI = 2 (dense only): EPI = 0 + row sums of the
 // stored output for the next LayerNorm (ca_gemm_args.row_sums_out), one partial sum per 80-column wave quarter.
@@ -176,6 +184,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
   // either: instruction issue is in order, a 40-instruction piece only overlaps the last MFMA before it.)
   auto issue_tile = [&]() __attribute__((always_inline)) {
     if (!d_live) return;
+    if (CA_PQ_ABL(1) && d_n >= 2) {
+      ++d_n;
+      ++d_t;
+      return;
+    }
     const int par = d_n & 1;
     u16* buf = smem + par * BUF;
     const unsigned wk = (unsigned)(d_tap * kc + d_c0) * 2u;  // weights: K runs over (tap, channel)
@@ -244,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
   // (bounded: a hung wave would take the whole device down; wrong results are caught by the tests, a hang is not)
   auto flag_finish = [&](int slot, int seqno, unsigned fv) __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fv)::"memory");
+    if (CA_PQ_ABL(1)) return;
     const unsigned want = (unsigned)(seqno & 1023);
     if ((unsigned)__builtin_amdgcn_readfirstlane(fv) == want) return;
     const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(my_flags + slot * 256);
@@ -270,7 +284,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
     fb1_base = OFF_B1 + rb1 * KT + ((g ^ swz(rb1)) << 3);
   }
   u32x4 fa[TM], fb[TN];
+  if (CA_PQ_ABL(2)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = (u32x4){(unsigned)lane * 0x9E3779B9u + i, (unsigned)lane * 0x85EBCA6Bu, (unsigned)lane * 0xC2B2AE35u, (unsigned)lane * 0x27D4EB2Fu} & 0x3BFF3BFFu;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = (u32x4){(unsigned)lane * 0x165667B1u + j, (unsigned)lane * 0xD3A2646Cu, (unsigned)lane * 0xFD7046C5u, (unsigned)lane * 0xB55A4F09u} & 0x3BFF3BFFu;
+  }
   auto read_frags = [&](const u16* buf, int s) __attribute__((always_inline)) {
+    if (CA_PQ_ABL(2)) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[j]));
+      return;
+    }
     const int x = s ? 32 : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[i] = ld16(buf + (fa_base ^ x) + i * 16 * KT);
@@ -280,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
     for (int j = 0; j < 3; ++j) fb[2 + j] = ld16(buf + (fb1_base ^ x) + j * 16 * KT);
   };
   auto mfma_all = [&]() __attribute__((always_inline)) {
+    if (CA_PQ_ABL(4)) return;
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -512,11 +540,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
       if (!g1_late) advance_and_issue();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       stamp(2);
-      __builtin_amdgcn_s_barrier();
+      if (!CA_PQ_ABL(8)) __builtin_amdgcn_s_barrier();
       stamp(3);
       mfma_all();
       stamp(4);
-      __builtin_amdgcn_s_barrier();
+      if (!CA_PQ_ABL(8)) __builtin_amdgcn_s_barrier();
       stamp(5);
       // ---- reads of k half 1; group 1 confirms its pieces of K tile cv + 1 behind them (group 0 reads that tile in the
       // interval after group 1's next barrier)
@@ -527,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
       if (wr == 1 && cv + 1 < total_kt) flag_finish(par ^ 1, cv + 1, fl);
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       stamp(6);
-      __builtin_amdgcn_s_barrier();
+      if (!CA_PQ_ABL(8)) __builtin_amdgcn_s_barrier();
       stamp(7);
       // ---- MFMAs of k half 1; group 0 confirms its pieces of K tile cv + 1 behind them
       if (g1_late) advance_and_issue();
@@ -535,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
       mfma_all();
       if (wr == 0 && cv + 1 < total_kt) flag_finish(par ^ 1, cv + 1, fl);
       stamp(8);
-      __builtin_amdgcn_s_barrier();
+      if (!CA_PQ_ABL(8)) __builtin_amdgcn_s_barrier();
       ++cv;
     }
     // both groups' epilogues in the same interval (ca_gemm_ps.h): one extra barrier for group 0 before, for group 1 after
