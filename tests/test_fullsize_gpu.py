@@ -146,3 +146,45 @@ def test_config2_size_properties():
     # the ControlNet really contributes
     eps_d = unet.forward_nhwc(x2, 2, f, 481, prompt_same)
     assert rel(eps_d, eps_a) > 1e-3
+
+
+def test_config2_step_repeats_bit_identically_with_the_controlnet_stream_beside_the_unet():
+    """tools/determinism_stress.py inside the suite: the full config-2 step as the product runs it -- ControlNet stack on the
+    second HIP stream while the UNet encoder runs, residual adds in the zero convolutions' epilogues -- eight times; every
+    eps (which the 13 residuals enter) equals the first, bit for bit.  (The streaming kernels confirm their global -> LDS
+    units through LDS flags and the two streams compete for CUs: a race would show up as a differing repeat.)"""
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.configs import controlnet_config, unet_config
+    from controlanimate_amd.controlnet import ControlNetModel
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.unet import UNet3DConditionModel
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        unet = UNet3DConditionModel.from_config(unet_config("v2"))
+        net = ControlNetModel.from_config(controlnet_config())
+    for mod in (unet, net):
+        for p in mod.parameters():
+            if p.dim() > 1 and float(p.detach().abs().max()) == 0.0:
+                p.data.normal_(std=0.02)
+    unet.prepare(DEV, torch.float16)
+    net.prepare(DEV, torch.float16)
+    f, hw = 16, 64
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(1, 4, f, hw, hw, generator=g).to(DEV)
+    prompt = (torch.randn(2, 77, 768, generator=g) * 0.5).to(DEV)
+    cn = MultiControlNetResidualsPipeline(["c"], [1.0], use_lcm=False, controlnets=[net], device=DEV)  # (hints doubled: ControlNet batch 32)
+    cn.prep_control_images([h for h in torch.rand(f, 3, 512, 512, generator=g)], do_classifier_free_guidance=True, guess_mode=False)
+    x2 = K.latents_to_nhwc(lat, unet.conv_in.cin_pad, 2, 1.0, torch.float16)
+    t = torch.full((1,), 481.0, device=DEV)
+
+    def step():
+        # (the calls of ControlAnimationPipeline's model_eps: both CFG halves of the latents are the same tensor)
+        down = cn.residuals_nhwc_async(x2, t, prompt, False, cfg_identical_halves=True, fuse_images=x2.shape[0])
+        eps = unet.forward_nhwc(x2, 2, f, t, prompt, down, None, cfg_identical_halves=True)
+        torch.cuda.synchronize()
+        return eps.clone()
+
+    first = step()
+    assert torch.isfinite(first).all()
+    differing = sum(int(not torch.equal(step(), first)) for _ in range(8))
+    assert differing == 0, f"{differing} of 8 repeats differ from the first"
