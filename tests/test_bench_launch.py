@@ -45,3 +45,31 @@ def test_failing_rank_fails_the_launch():
         pytest.skip("GPU present: the real path would run")
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """profiles/round3_bench.json is a `python bench.py` line of the final code: the keys the driver reads are there and the
+    numbers are consistent with each other (value = frames per window / (steps x s per step), roofline.frac = achieved / peak,
+    HBM traffic per launch not below what the dominant kernel must move at least once)."""
+    path = os.path.join(ROOT, "profiles", "round3_bench.json")
+    d = json.load(open(path))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "frames_per_sec" and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    cfg = d["config"]
+    assert "workload" in cfg and "model" not in cfg and cfg["baseline_config"] == 2
+    fps = cfg["frames_per_window"] / (cfg["steps_per_window"] * d["ms_per_step"] * 1e-3)
+    assert abs(fps - d["value"]) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"]
+    m = r["matrix_rate_vs_operand_data"]  # the matrix pipes' rate on real data on the same box (DESIGN.md section 3)
+    assert m["vendor_gemm_8192x8192x8192"]["zero_data"] > m["vendor_gemm_8192x8192x8192"]["normal_data"] > 0
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    assert c["config2_step"]["sec_per_step"] > 100 * d["ms_per_step"] * 1e-3  # the CPU port beside it, never the target
