@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CA_HIP_LIB") or os.path.join(_HERE, "csrc", "libcontr
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class CAHipUnavailable(RuntimeError):
@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("row_sums_out", C.c_void_p), ("ln_parts", C.c_int32),
+        ("w_frag", C.c_void_p),
     ]
 
 
@@ -95,6 +96,7 @@ SYMBOLS = {
     "ca_abi_version": (C.c_int, []),
     "ca_last_error": (C.c_char_p, []),
     "ca_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "ca_pack_w_frag": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ca_gemm_ln_inline_supported": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_gemm_wants_finished_stats": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_ln_finish_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

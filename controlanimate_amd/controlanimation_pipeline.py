@@ -222,6 +222,38 @@ class ControlAnimationPipeline:
             video = torch.stack(frames, dim=2)
         return (video / 2 + 0.5).clamp(0, 1).cpu().float().numpy()
 
+    # ---- what a captured hipGraph of the step reads besides its own pool ---------------------------------------------
+    @staticmethod
+    def _model_cache_owners(unet, nets):
+        """Strong references to the buffers a captured step reads but the pipeline does not allocate: the models' per-window
+        caches (prompt copy + text / IP K/V dict, hint embeddings) and their weight arenas, as they are at capture time."""
+        return {"unet": (unet._cache, unet._cache.get("ehs"), unet.arena),
+                "nets": [(n._cache, n._cache.get("ehs"), n._hint_emb, None if n._hint_key is None else n._hint_key[0], n.arena)
+                         for n in nets]}
+
+    @staticmethod
+    def _graph_owns_model_caches(gs, unet, nets, cn) -> bool:
+        """True while every such buffer is still the object the graph was captured on AND still keyed on the pipeline's
+        static prompt / control-image tensors (so that `refresh_window_caches` refreshes from the right source)."""
+        own = gs.get("owned")
+        if own is None:
+            return False
+        c, ehs, arena = own["unet"]
+        key = unet._cache_key
+        if unet._cache is not c or c.get("ehs") is not ehs or unet.arena is not arena or key is None or key[0] is not gs["unet_prompt"]:
+            return False
+        if len(own["nets"]) != len(nets):
+            return False
+        for k_, (n, (c, ehs, hint, hint_src, arena)) in enumerate(zip(nets, own["nets"])):
+            key = n._cache_key
+            if n._cache is not c or c.get("ehs") is not ehs or n.arena is not arena or key is None or key[0] is not gs["cn_prompt"]:
+                return False
+            if n._hint_emb is not hint or n._hint_key is None or n._hint_key[0] is not hint_src:
+                return False
+            if cn is None or cn.prep_images is None or cn.prep_images[k_] is not hint_src:
+                return False
+        return True
+
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, video_length: Optional[int], input_frames: list = None, prompt=None, height: Optional[int] = None,
@@ -330,7 +362,10 @@ class ControlAnimationPipeline:
             gs = self._graph_state
             if gs is None or gs["sig"] != sig:
                 gs = self._graph_state = {
-                    "sig": sig, "graph": None, "eps": None,
+                    "sig": sig, "graph": None, "eps": None, "owned": None,
+                    # the signature holds ids: keep the objects alive so that an id cannot be reused by another object
+                    "keep": (unet, unet.arena, tuple(nets), tuple(n.arena for n in nets), cn,
+                             tuple(cn.prep_images) if cn is not None else None),
                     "x": torch.empty((rep * f, hh, ww, cpad), device=device, dtype=unet.act_dtype),
                     "t": torch.zeros(1, device=device, dtype=torch.float32),
                     "unet_prompt": torch.empty_like(unet_prompt), "cn_prompt": torch.empty_like(cn_prompt),
@@ -341,6 +376,11 @@ class ControlAnimationPipeline:
             if w_embedding is not None:
                 gs["w"].copy_(w_embedding)
             unet_prompt, cn_prompt, w_embedding = gs["unet_prompt"], gs["cn_prompt"], gs["w"]
+            if gs["graph"] is not None and not self._graph_owns_model_caches(gs, unet, nets, cn):
+                # an eager forward of the same models in between (another prompt tensor, a one-step call, a second pipeline
+                # sharing the UNet) replaced the caches the captured kernels read: their buffers may be freed or stale
+                logger.info("the models' per-window caches changed hands since the hipGraph was captured: capturing again")
+                gs["graph"] = gs["eps"] = gs["owned"] = None
             if gs["graph"] is not None:  # a later window: the per-window caches (text / IP K/V, hint embeddings), in place
                 unet.refresh_window_caches()
                 for n_ in nets:
@@ -406,6 +446,7 @@ class ControlAnimationPipeline:
                         with torch.cuda.graph(g_):
                             gs["eps"] = model_eps(gs["x"], gs["t"])
                         gs["graph"] = g_
+                        gs["owned"] = self._model_cache_owners(unet, nets)
                     except Exception as exc:  # capture is an optimisation only -- but never a silent one
                         use_graph = False
                         self._graph_state = None

@@ -185,13 +185,23 @@ __global__ __launch_bounds__(256) void k_repeat(const u32x4* __restrict__ src, u
     for (int t = 0; t < times; ++t) dst[(int64_t)t * n16 + i] = v;
   }
 }
+// any size / alignment (odd reduced-width shapes, views with a storage offset): byte granular
+__global__ __launch_bounds__(256) void k_repeat_bytes(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int64_t n, int times) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const unsigned char v = src[i];
+    for (int t = 0; t < times; ++t) dst[(int64_t)t * n + i] = v;
+  }
+}
 }  // namespace
 
 extern "C" int ca_repeat(const void* src, void* dst, int64_t bytes, int32_t times, void* stream) {
   CA_REQUIRE(src && dst, "ca_repeat: null operand");
-  CA_REQUIRE(bytes > 0 && bytes % 16 == 0 && times >= 1 && times <= 64, "ca_repeat: bytes=%lld (multiple of 16) times=%d", (long long)bytes, times);
-  CA_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "ca_repeat: operands must be 16-byte aligned");
-  hipLaunchKernelGGL(k_repeat, dim3(blocks_for(bytes / 16, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, bytes / 16, times);
+  CA_REQUIRE(bytes > 0 && times >= 1 && times <= 64, "ca_repeat: bytes=%lld times=%d (1..64)", (long long)bytes, times);
+  if (bytes % 16 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0)
+    hipLaunchKernelGGL(k_repeat, dim3(blocks_for(bytes / 16, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, bytes / 16, times);
+  else
+    hipLaunchKernelGGL(k_repeat_bytes, dim3(blocks_for(bytes, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src,
+                       (unsigned char*)dst, bytes, times);
   CA_CHECK_LAUNCH("ca_repeat");
   return CA_OK;
 }

@@ -449,6 +449,20 @@ inline bool wres_eligible(const GemmKParams& p) {
          (wres_env == 1 || p.m >= 16384);
 }
 
+// Activation-resident kernel (ca_gemm_ar.h, round 4): the same K = 320 launches when the caller also hands over W in fragment
+// order (ca_gemm_args.w_frag).  A subset of what the weight-resident kernel takes: one A source, N a multiple of 64 (64-column
+// panels dealt to four waves), alpha = post = 1, no activation, residual only without LayerNorm / GEGLU, row-bias groups of whole
+// 128-row tiles; in-kernel LayerNorm statistics need the caller's scratch (p.partial: 8 M bytes).
+// CA_GEMM_AR (experiment builds): 0 = never, 1 = every launch it can take (also N = 320), default: N >= 960.
+inline bool ar_eligible(const GemmKParams& p) {
+  static const int ar_env = CA_KNOB("CA_GEMM_AR", -1);
+  if (ar_env == 0 || !p.wf || !wres_eligible(p)) return false;
+  return p.c2 == 0 && p.n % 64 == 0 && p.alpha == 1.f && p.post == 1.f && p.act == CA_ACT_NONE && !p.row_sums && ((uintptr_t)p.wf & 15) == 0 &&
+         ((uintptr_t)p.c & 15) == 0 && p.ldc % 8 == 0 && (!p.res || (((uintptr_t)p.res & 15) == 0 && p.ld_res % 8 == 0 && !p.geglu && !p.ln_colsum)) &&
+         (!p.rowbias || (p.rows_per_group % 128 == 0 && !p.geglu)) && (!p.ln_inline || p.partial) &&
+         (ar_env == 1 || p.n >= 960);
+}
+
 // Dense GEMMs of the 8x8-latent level (M = 2048: 160 tiles of 128x128 for 256 CUs, each walking its 20..80 K tiles
 // alone at one DMA round trip per tile): the same slab schedule as the small convolutions.
 inline int splitk_plan_dense(int m, int n, int nt, int geglu, int out_f32) {
@@ -477,6 +491,7 @@ enum PlanKind {
   PK_REG,         // k_gemm<bm, bn>: register-staged (channel counts the DMA path cannot take)
   PK_PS,          // persistent streaming kernel, 128 x 320 tiles (ca_gemm_ps.h)
   PK_PQ,          // persistent streaming kernel, 256 x 320 tiles / 128 x 80 wave tiles (ca_gemm_pq.h)
+  PK_AR,          // activation-resident kernel, 128-row tiles / 128 x 80 wave tiles, W fragments from L2 (ca_gemm_ar.h)
   PK_EXP,         // experiment builds only: `exp` selects (see launch_gemm)
 };
 struct GemmPlan {
@@ -588,6 +603,11 @@ inline GemmPlan plan_gemm(const GemmKParams& p, int mode, bool allow_pq = true) 
       return g;
     }
   }
+  if (mode == 0 && dma && ar_eligible(p)) {
+    g.kind = PK_AR;
+    g.bm = 128, g.bn = 64;
+    return g;
+  }
   if (mode == 0 && dma && wres_eligible(p)) {
     g.kind = PK_WRES;
     g.bm = 256, g.bn = 160;
@@ -684,6 +704,7 @@ inline bool row_sums_capable(const GemmKParams& p) { return row_sums_parts_of(p)
 inline void plan_label(const GemmPlan& g, char* buf, int len) {
   switch (g.kind) {
     case PK_WRES: snprintf(buf, len, "wres160"); break;
+    case PK_AR: snprintf(buf, len, "ar128x64"); break;
     case PK_PP2: snprintf(buf, len, "pp128x320"); break;
     case PK_PS: snprintf(buf, len, "ps128x320"); break;
     case PK_PQ: snprintf(buf, len, "pq256x320"); break;
@@ -701,6 +722,7 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
   const dim3 grid(ceil_div_i(p.m, g.bm ? g.bm : 128) * ceil_div_i(p.n, g.bn ? g.bn : 128));
   switch (g.kind) {
     case PK_WRES: return ca_launch_gemm_pp(p, DT, MODE, 160, 0u, st);
+    case PK_AR: return ca_launch_gemm_ar(p, DT, st);
     case PK_PP2: return ca_launch_gemm_pp(p, DT, MODE, 320, g.tiles, st);
     case PK_PS: return ca_launch_gemm_pp(p, DT, MODE, 322, g.tiles, st);
     case PK_PQ: return ca_launch_gemm_pp(p, DT, MODE, 323, g.tiles, st);
@@ -789,6 +811,7 @@ static int gemm_fill(const ca_gemm_args* a, GemmKParams& p) {
   CA_REQUIRE(a->ln_parts == 0 || (a->ln_stats && a->ln_colsum && a->ln_eps > 0.f), "ca_gemm: ln_parts needs ln_stats (the partial sums), ln_colsum and ln_eps > 0");
   p.ln_inline = (a->ln_colsum && !a->ln_stats) ? 1 : 0;
   p.ln_eps = a->ln_eps;
+  p.wf = (const u16*)a->w_frag;
   CA_REQUIRE(!a->ln_stats || a->ln_colsum, "ca_gemm: ln_stats without ln_colsum");
   CA_REQUIRE(!p.ln_inline || a->ln_eps > 0.f, "ca_gemm: ln_colsum without ln_stats asks for in-kernel statistics and needs ln_eps > 0");
   CA_REQUIRE(!a->ln_colsum || (a->n >= 8 && a->k2 == 0), "ca_gemm: the folded LayerNorm needs N >= 8 and a single A source");
@@ -830,6 +853,7 @@ static int gemm_prepare(const ca_gemm_args* a, GemmKParams& p) {
       p.partial = reinterpret_cast<float*>(a->workspace);
     }
   }
+  if (p.ln_inline && p.wf && a->workspace && a->workspace_bytes >= (int64_t)p.m * 8) p.partial = reinterpret_cast<float*>(a->workspace);  // (mean, rstd) scratch of k_gemm_ar
   CA_REQUIRE(!p.row_sums || row_sums_capable(p), "ca_gemm: row_sums_out is not available for this launch: ask ca_gemm_row_sums_parts() first");
   CA_REQUIRE(!p.ln_inline || wres_eligible(p), "ca_gemm: in-kernel LayerNorm statistics (ln_stats NULL) are not available for this launch: "
              "ask ca_gemm_ln_inline_supported() first and pass ln_stats otherwise");
@@ -850,6 +874,13 @@ extern "C" int ca_gemm(const ca_gemm_args* a, void* stream) {
 extern "C" int64_t ca_gemm_workspace_bytes(const ca_gemm_args* a) {
   if (!a || a->m <= 0 || a->n <= 0 || a->k1 <= 0 || a->k2 < 0) return 0;
   const int kc = a->k1 + a->k2;
+  if (a->ln_colsum && !a->ln_stats && a->w_frag && !a->ln_parts && !a->row_sums_out) {
+    // in-kernel LayerNorm statistics of the activation-resident kernel: (mean, rstd) per row
+    GemmKParams p{};
+    if (gemm_fill(a, p) != CA_OK) return 0;
+    p.partial = reinterpret_cast<float*>(uintptr_t(16));  // "a scratch is there": would the launch take that kernel?
+    return ar_eligible(p) ? (int64_t)a->m * 8 : 0;
+  }
   if (kc % BK != 0 || (a->k2 != 0 && a->k1 % BK != 0) || (a->ln_colsum && !a->ln_stats) || a->ln_parts || a->row_sums_out) return 0;
   const int s = splitk_plan_dense(a->m, a->n, ceil_div_i(kc, BK), a->geglu, a->out_f32);
   return s > 1 ? (int64_t)s * a->m * a->n * 4 : 0;

@@ -38,8 +38,9 @@ struct GemmKParams {
   int tap_inner;  // K-tile order of the implicit-GEMM convolution (see k_tile_split)
   float* row_sums;  // producer side: [M][N / 320] (sum, sum of squares) of the STORED output rows per 320-column tile (k_gemm_pp2 only)
   int ln_parts;     // consumer side: ln_stats holds [M][ln_parts] such partial sums, finished here with ln_eps; 0: (mean, rstd)
-  int ln_inline;  // ln_colsum without ln_stats: the kernel computes (mean, rstd) of the A rows itself (k_gemm_wres only)
+  int ln_inline;  // ln_colsum without ln_stats: the kernel computes (mean, rstd) of the A rows itself (k_gemm_wres, k_gemm_ar)
   float ln_eps;
+  const u16* wf;  // ABI v9: W once more in MFMA-fragment order (ca_pack_w_frag), or NULL: the activation-resident kernel reads it
 };
 
 constexpr int BK = 64;
@@ -387,3 +388,4 @@ constexpr unsigned DMA_OOB = 0xFFFFFFF0u;  // beyond any descriptor size we acce
 
 // ping-pong 256 x BN kernel family (ca_gemm_pp.hip); bn = 256 | 128
 int ca_launch_gemm_pp(const ca_gemm_detail::GemmKParams& p, int dtype, int mode, int bn, unsigned tiles, hipStream_t st);
+int ca_launch_gemm_ar(const ca_gemm_detail::GemmKParams& p, int dtype, hipStream_t st);  // ca_gemm_ar.hip

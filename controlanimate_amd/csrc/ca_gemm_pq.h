@@ -267,6 +267,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
       if ((unsigned)__builtin_amdgcn_readfirstlane(v) == want) return;
     }
+    // gave up polling (a pre-empted or very slow DMA): loads return in order, so draining the wave's VMEM counter is the
+    // correct -- merely slower -- way to know the unit has landed; never continue on stale LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   // ---------------------------------------------------------------- compute side

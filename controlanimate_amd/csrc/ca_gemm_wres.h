@@ -144,6 +144,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_wres(GemmKParams p, int panels,
       if ((unsigned)__builtin_amdgcn_readfirstlane(v) == want) return;
       __builtin_amdgcn_s_sleep(1);
     }
+    // gave up polling (a pre-empted or very slow DMA): loads return in order, so draining the wave's VMEM counter is the
+    // correct -- merely slower -- way to know the chunk has landed; never continue on stale LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   int r_n = 0;  // chunk computed next
 

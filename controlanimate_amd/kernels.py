@@ -83,6 +83,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
                     m=m, n=n, k1=k1, k2=k2, rows_per_group=rows_per_group, alpha=alpha,
                     post_scale=post_scale, act=act, geglu=int(geglu), out_f32=int(out_f32),
                     dtype=dt_code(a.dtype))
+    frag = getattr(w, "_frag", None)  # (tensor, geglu flag it was packed for): attach_w_frag
+    if frag is not None and frag[1] == bool(geglu) and _AR_ON:
+        args.w_frag = _p(frag[0])
     if ln is not None:
         st, cs = ln
         assert cs.dtype == torch.float32 and cs.numel() == n
@@ -128,6 +131,22 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     _record_plan(lib().ca_gemm_plan_name, args)
     check(lib().ca_gemm(C.byref(args), _stream()), "ca_gemm")
     return out
+
+
+_AR_ON = os.environ.get("CA_GEMM_AR_PY", "1") != "0"  # (0: never hand the fragment-ordered weights over -- A/B runs)
+
+
+def attach_w_frag(w: torch.Tensor, geglu: bool = False) -> torch.Tensor:
+    """Gives a packed [N, 320] weight its fragment-ordered twin (ca_pack_w_frag, ABI v9): `gemm` hands both over and the K = 320
+    projections of the 64x64-latent level run on the activation-resident kernel.  No-op for shapes that kernel cannot take.
+    Called once per weight at prepare() time; the twin lives beside the arena (N x 640 bytes)."""
+    _req_cuda(w)
+    if w.dim() != 2 or w.shape[1] != 320 or w.shape[0] % 320 != 0 or not w.is_contiguous() or w.dtype not in (torch.float16, torch.bfloat16):
+        return w
+    dst = torch.empty_like(w)
+    check(lib().ca_pack_w_frag(w.data_ptr(), w.shape[0], w.shape[1], int(bool(geglu)), dst.data_ptr(), _stream()), "ca_pack_w_frag")
+    w._frag = (dst, bool(geglu))
+    return w
 
 
 _ROW_SUMS_ON = os.environ.get("CA_LN_ROWSUMS", "1") != "0"  # (0: always the separate statistics pass -- A/B runs)
@@ -344,7 +363,10 @@ def repeat_batch(x: torch.Tensor, times: int = 2) -> torch.Tensor:
     if not _REPEAT_ON:
         return torch.cat([x] * times)
     _req_cuda(x)
-    assert x.is_contiguous() and (x.numel() * x.element_size()) % 16 == 0
+    if not x.is_contiguous():
+        x = x.contiguous()  # (a strided view: one gather first; sizes / alignments the 16-byte kernel cannot take go byte-wise in the library)
+    if x.numel() == 0:
+        return x.new_empty((times * x.shape[0],) + tuple(x.shape[1:]))
     out = torch.empty((times * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
     check(lib().ca_repeat(x.data_ptr(), out.data_ptr(), x.numel() * x.element_size(), times, _stream()), "ca_repeat")
     return out

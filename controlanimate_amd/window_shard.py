@@ -66,6 +66,18 @@ def broadcast_weights(buffers: Sequence[torch.Tensor], src: int = 0) -> int:
     Returns the number of bytes moved. No-op for a single process."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
+    # every rank must hand over the same list -- a rank whose skeleton packs one tensor more, less or differently would
+    # otherwise hang in a broadcast or run on garbage weights: compare (numel, dtype) manifests first, on ALL ranks, so that
+    # every rank raises together instead of some waiting forever
+    manifest = [(int(b.numel()), str(b.dtype)) for b in buffers]
+    everyone: List[Optional[list]] = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, manifest)
+    for r, other in enumerate(everyone):
+        if other != everyone[src]:
+            diff = next((i for i, (x, y) in enumerate(zip(other, everyone[src])) if x != y), min(len(other), len(everyone[src])))
+            raise RuntimeError(f"broadcast_weights: rank {r} holds {len(other)} weight buffers, rank {src} {len(everyone[src])}; "
+                               f"first difference at index {diff}: {other[diff] if diff < len(other) else None} vs "
+                               f"{everyone[src][diff] if diff < len(everyone[src]) else None}")
     total = 0
     for buf in buffers:
         dist.broadcast(buf, src=src)

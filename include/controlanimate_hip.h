@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 8
+#define CA_ABI_VERSION 9
 
 /* element types */
 #define CA_BF16 0
@@ -121,8 +121,19 @@ typedef struct ca_gemm_args {
    *             sums in order and finishes mean / rstd = 1 / sqrt(var + ln_eps) itself (K of the consumer = the row width). */
   float* row_sums_out;
   int32_t ln_parts;
+  /* ABI v9: `w` once more in MFMA-fragment order (written by ca_pack_w_frag(w, n, k, geglu, ...) with the SAME geglu flag as
+   * this call), or NULL.  With it the K = 320 projections of the 64x64-latent level (M >= 16384, N % 320 == 0, N >= 960, one A source,
+   * alpha = post_scale = 1, no activation: q|k|v, the GEGLU projection -- animatediff/models/attention.py:214-237,303-357,
+   * motion_module.py:203-224) run on the activation-resident kernel, whose waves read W fragments straight from L2; `w` is
+   * still what every other plan reads.  With ln_colsum set and ln_stats NULL that kernel leaves its (mean, rstd) in
+   * `workspace` (ca_gemm_workspace_bytes = 8 M); without the workspace the launch keeps the weight-resident kernel. */
+  const void* w_frag;
 } ca_gemm_args;
 int ca_gemm(const ca_gemm_args* args, void* stream);
+/* ABI v9: dst[n * k] = the fragment-ordered copy of w[n, k] (k = 320, n % 64 == 0, 16-bit elements, 16-byte aligned) that
+ * ca_gemm_args.w_frag takes; geglu = the flag of the ca_gemm calls that will use it (the weight-row interleave behind the
+ * 16-byte stores differs).  Weights are packed once per model, so this runs at load time. */
+int ca_pack_w_frag(const void* w, int32_t n, int32_t k, int32_t geglu, void* dst, void* stream);
 /* bytes of split-K scratch this launch can use (0: it would not split) */
 int64_t ca_gemm_workspace_bytes(const ca_gemm_args* args);
 /* partial sums per row this launch can leave in row_sums_out (0: it cannot).  N / 320 on the 128 x 320-tile kernels; ABI v8:
@@ -311,7 +322,8 @@ int ca_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t b_p
                  int32_t dtype, void* stream);
 /* ABI v8: dst = `times` copies of the `bytes` of src behind each other (one read of src): torch.cat([x] * times) along the
  * leading dimension -- the reference's torch.cat([latents] * 2) (animatediff/pipelines/controlanimation_pipeline.py:797) makes
- * the two CFG halves identical, the shared prefix is computed once and repeated here.  bytes % 16 == 0, 16-byte aligned. */
+ * the two CFG halves identical, the shared prefix is computed once and repeated here.  16-byte vector copies when bytes % 16 == 0
+ * and both pointers are 16-byte aligned, a byte-granular kernel otherwise (any size, any alignment). */
 int ca_repeat(const void* src, void* dst, int64_t bytes, int32_t times, void* stream);
 
 /* y[r, :] = softmax(scale * x[r, :]) for an fp32 score matrix, written in `dtype`.

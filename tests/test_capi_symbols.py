@@ -135,8 +135,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu(capi):
     expect(lib.ca_lincomb(fake, ptrs, cf, 2, 0, None), "ca_lincomb")                                               # n = 0
     expect(lib.ca_lincomb(None, ptrs, cf, 2, 64, None), "ca_lincomb")
     # ABI v8
-    expect(lib.ca_repeat(fake, C.c_void_p(0x2000), 24, 2, None), "ca_repeat")                                       # bytes % 16
-    expect(lib.ca_repeat(fake, C.c_void_p(0x2008), 64, 2, None), "ca_repeat")                                       # alignment
+    expect(lib.ca_repeat(fake, C.c_void_p(0x2000), 0, 2, None), "ca_repeat")                                        # bytes
+    expect(lib.ca_repeat(fake, C.c_void_p(0x2008), 64, 65, None), "ca_repeat")                                      # times
     expect(lib.ca_repeat(None, fake, 64, 2, None), "ca_repeat")
     expect(lib.ca_ln_finish_sums(fake, 0, 64, 640, 1e-5, fake, None), "ca_ln_finish_sums")                          # parts
     expect(lib.ca_ln_finish_sums(None, 2, 64, 640, 1e-5, fake, None), "ca_ln_finish_sums")

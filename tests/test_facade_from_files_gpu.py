@@ -39,3 +39,42 @@ def test_weighted_prompt_through_the_hip_text_encoder(model_tree):  # noqa: F811
     z0 = pipe._encode_plain("").float()
     assert float(w.max()) == pytest.approx(1.21) and not torch.equal(up, plain)
     assert torch.allclose(up, z0 + (plain - z0) * w.to(plain.device)[..., None], atol=2e-3)
+
+
+def test_skeleton_rank_receives_the_weights_and_reproduces_the_frames(model_tree):  # noqa: F811
+    """Ranks > 0 of `vid2vid.run_video_sharded` build `ControlAnimatePipeline(config, skeleton=True)`: same modules, same arenas,
+    NO weight file read (local_models.skeleton_weights), then receive `weight_buffers()` from rank 0.  That only works when both
+    sides list the same tensors in the same order with the same shapes -- checked here on one GPU: identical arena layouts and
+    manifests, different contents before the copy (the skeleton really read nothing), and bit-identical frames after copying the
+    buffers over (what the broadcast does)."""
+    import torch
+    from PIL import Image
+    from controlanimate_amd import local_models
+    from controlanimate_amd.controlanimate_pipeline import ControlAnimatePipeline
+    cfg = _config(model_tree)
+    full = ControlAnimatePipeline(cfg)
+    reads = []
+    orig = local_models.read_checkpoint
+    local_models.read_checkpoint = lambda *a, **k: (reads.append(a), orig(*a, **k))[1]
+    try:
+        skel = ControlAnimatePipeline(cfg, skeleton=True)
+    finally:
+        local_models.read_checkpoint = orig
+    assert not reads, f"the skeleton read weight files: {reads}"
+    assert not local_models.is_skeleton()  # the process-global flag is restored
+    bf, bs = full.weight_buffers(), skel.weight_buffers()
+    assert [(tuple(b.shape), b.dtype) for b in bf] == [(tuple(b.shape), b.dtype) for b in bs] and len(bf) >= 4
+
+    def layout(p):
+        models = [p.pipeline.unet] + list(p.multicontrolnetresiduals_pipeline.controlnets) + [p.pipeline.vae, p.pipeline.text_encoder]
+        return [[(it.offset, it.nbytes, tuple(it.shape), it.dtype) for it in m.arena.items] for m in models if m is not None]
+
+    assert layout(full) == layout(skel)
+    assert any(not torch.equal(a, b) for a, b in zip(bf, bs))  # random init vs checkpoint contents
+    for a, b in zip(bf, bs):
+        b.copy_(a)
+    rng = np.random.default_rng(5)
+    frames = [Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)) for _ in range(4)]
+    out_f, out_s = full.animate(frames, None, cfg), skel.animate(frames, None, cfg)
+    a, b = np.stack([np.asarray(x) for x in out_f]), np.stack([np.asarray(x) for x in out_s])
+    assert a.std() > 0 and np.array_equal(a, b)

@@ -136,6 +136,75 @@ def test_pipeline_graph_persists_across_windows(scenario):
     assert not torch.equal(runs[0][per - 1], runs[0][2 * per - 1])
 
 
+@pytest.mark.parametrize("intruder", ["one_step_call", "second_pipeline", "direct_forward"])
+def test_graph_survives_an_eager_forward_between_windows(intruder):
+    """The captured step reads buffers the models own (prompt copy, text K/V, hint embeddings).  Any eager forward of the
+    same models between two windows with ANOTHER prompt tensor replaces those caches -- a one-step call of the same pipeline
+    (no graph for a single step), a second pipeline sharing the UNet and ControlNet, or a direct `forward_nhwc` / ControlNet
+    call.  The next window must notice (`_graph_owns_model_caches`), capture again and still equal the all-eager run bit for
+    bit; before round 4 it replayed kernels that read the freed / stale K/V."""
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+    from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.schedulers import get_scheduler
+    from tests.test_pipeline_gpu import build
+    ucfg, uw, unet, ccfg, cws, nets = build("v2", seed=71, n_controlnets=1)
+    f, hw, nsteps = 8, 8, 4
+    g = torch.Generator().manual_seed(29)
+    mk = lambda: dict(pos=torch.randn(1, 77, 768, generator=g) * 0.5, neg=torch.randn(1, 77, 768, generator=g) * 0.5,
+                      hints=torch.rand(f, 3, 8 * hw, 8 * hw, generator=g), lat=torch.randn(1, 4, f, hw, hw, generator=g) * 0.8)
+    windows, other = [mk() for _ in range(3)], mk()
+
+    def call(pipe, cn, w, steps, gen, **kw):
+        return pipe(video_length=f, input_frames=None, height=8 * hw, width=8 * hw, num_inference_steps=nsteps, strength=1.0,
+                    guidance_scale=1.3, generator=gen, multicontrolnetresiduals_pipeline=cn, prompt_embeds=w["pos"],
+                    negative_prompt_embeds=w["neg"], use_lcm=False, guess_mode=False, input_latents=w["lat"],
+                    control_images={"n0": [h for h in w["hints"]]}, output_type="latent",
+                    callback=lambda i, t, l: steps.append(l.clone()), **kw).videos
+
+    runs = []
+    for use_graph in (False, True):
+        pipe = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet,
+                                        scheduler=get_scheduler("LCMScheduler", **NOISE_SCHEDULER_KWARGS)).to(DEV)
+        pipe.use_hip_graph = use_graph
+        cn = MultiControlNetResidualsPipeline(["n0"], [0.8], use_lcm=False, controlnets=nets, device=DEV)
+        torch.manual_seed(3)
+        gen = torch.Generator(device="cpu").manual_seed(3)
+        steps, replays = [], []
+        for k, w in enumerate(windows):
+            steps.append(call(pipe, cn, w, steps, gen).clone())
+            replays.append(pipe.graph_replays)
+            torch.cuda.synchronize()
+            if k == 2:
+                break
+            # ---- the intruder: an eager forward of the same models with another prompt / other control frames
+            junk = []
+            if intruder == "one_step_call":
+                call(pipe, cn, other, junk, torch.Generator(device="cpu").manual_seed(5), step_range=(1, 2))
+            elif intruder == "second_pipeline":
+                p2 = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet,
+                                              scheduler=get_scheduler("LCMScheduler", **NOISE_SCHEDULER_KWARGS)).to(DEV)
+                p2.use_hip_graph = False
+                cn2 = MultiControlNetResidualsPipeline(["n0"], [0.8], use_lcm=False, controlnets=nets, device=DEV)
+                call(p2, cn2, other, junk, torch.Generator(device="cpu").manual_seed(5))
+            else:
+                x = torch.randn(2 * f, hw, hw, unet.conv_in.cin_pad, generator=g).half().to(DEV)
+                pr = torch.cat([other["neg"], other["pos"]]).to(DEV)
+                unet.forward_nhwc(x, 2, f, 500.0, pr, None, None)
+                nets[0].forward_body(x, 500.0, pr, torch.cat([other["hints"]] * 2).to(DEV))
+            torch.cuda.synchronize()
+            # garbage over whatever the allocator handed back: a replay that still reads freed K/V would now see NaN
+            trash = [torch.full((1 << 20,), float("nan"), device=DEV, dtype=torch.float16) for _ in range(64)]
+            del trash
+        if use_graph:
+            assert pipe.graph_fallback_reason is None
+            assert all(r >= nsteps - 1 for r in replays), replays  # every window still replays (after a re-capture)
+        runs.append(steps)
+    assert len(runs[0]) == len(runs[1]) >= 12
+    for k, (a, b) in enumerate(zip(runs[0], runs[1])):
+        assert torch.isfinite(b).all() and torch.equal(a, b), f"latents differ at record {k}"
+
+
 def test_fused_controlnet_adds_equal_the_separate_adds():
     """The reference's 13 `sample + residual` adds (unet.py:567-576, 584-585) inside the zero convolutions' epilogues
     (residuals_nhwc_async(fuse_images=...)) == 13 separate ca_add_bcast passes, bit for bit with one ControlNet (the zero

@@ -466,6 +466,16 @@ def test_repeat_batch_equals_torch_cat():
         x = rnd(*shape, dtype=dt, seed=3).to(DEV)
         for times in (2, 3):
             assert torch.equal(k.repeat_batch(x, times), torch.cat([x] * times))
+    # sizes / alignments / strides the 16-byte kernel cannot take (round-3 advice: these used to assert)
+    x = rnd(7, 3, 5, dtype=torch.float16, seed=4).to(DEV)                   # 210 bytes
+    assert torch.equal(k.repeat_batch(x), torch.cat([x, x]))
+    base = rnd(9, 8, 8, dtype=torch.float16, seed=5).to(DEV)
+    v = base[1:5]                                                          # contiguous view with a storage offset
+    assert torch.equal(k.repeat_batch(v, 3), torch.cat([v] * 3))
+    v = base.view(-1)[1:1 + 64].view(4, 16)                                 # 2-byte aligned start
+    assert v.data_ptr() % 16 != 0 and torch.equal(k.repeat_batch(v), torch.cat([v, v]))
+    v = base[:, :, ::2]                                                    # strided
+    assert torch.equal(k.repeat_batch(v), torch.cat([v, v]))
 
 
 def test_silu_and_timestep_embedding():

@@ -30,6 +30,12 @@ def _worker(rank, world, port, ret):
     moved = WS.broadcast_weights(bufs)
     assert moved == a0.numel() + a1.numel()
     assert torch.equal(bufs[0], a0) and torch.equal(bufs[1], a1)
+    # 1b) a rank whose buffer list differs (a skeleton that packs differently) makes EVERY rank raise -- nobody hangs
+    bad = [a0.clone(), a1.clone()] if rank == 0 else [a0.clone(), torch.zeros(1000, dtype=torch.uint8)]
+    with pytest.raises(RuntimeError, match="first difference at index 1"):
+        WS.broadcast_weights(bad)
+    with pytest.raises(RuntimeError, match="holds"):
+        WS.broadcast_weights([a0.clone()] if rank == 0 else [a0.clone(), a1.clone()])
     # 2) windows: deterministic function of the window index only -> any rank computes the same thing
     def run_window(i):
         gg = torch.Generator().manual_seed(1000 + i)

@@ -1,0 +1,152 @@
+"""Activation-resident K = 320 GEMM (ca_gemm_ar.h): correctness against fp32 torch and against the weight-resident kernel (the
+same call without the fragment-ordered weights), determinism, dispatch labels and timing -- one process, one box.
+    python tools/ar_check.py [--time-only]
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from controlanimate_amd import kernels as K
+
+dev = "cuda"
+
+
+def label(fn):
+    K._plan_sink = []
+    try:
+        fn()
+        return K._plan_sink[-1]
+    finally:
+        K._plan_sink = None
+
+
+def cases(dt):
+    g = torch.Generator(device="cpu").manual_seed(7)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev)
+    out = []
+    for (m, n) in [(16384 + 8, 960), (131072, 960), (16384 + 200, 2560), (32768, 1280), (20000, 320)]:
+        k = 320
+        a = rn(m, k).to(dt)
+        w = rn(n, k, scale=k ** -0.5).to(dt)
+        bias, res = rn(n), rn(m, n).to(dt)
+        st = torch.stack([a.float().mean(1), (a.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+        cs = w.float().sum(1).contiguous()
+        out.append((f"plain {m}x{n}", dict(a=a, w=w)))
+        out.append((f"bias+res {m}x{n}", dict(a=a, w=w, bias=bias, residual=res)))
+        out.append((f"LN fold {m}x{n}", dict(a=a, w=w, bias=bias, ln=(st, cs))))
+        out.append((f"LN fold inline {m}x{n}", dict(a=a, w=w, bias=bias, ln=("inline", cs), _ln_ref=st)))
+        if m % 128 == 0:
+            rpg = 4096
+            rb = rn((m + rpg - 1) // rpg, n)
+            out.append((f"LN inline + rowbias {m}x{n}", dict(a=a, w=w, bias=bias, rowbias=rb, rows_per_group=rpg, ln=("inline", cs), _ln_ref=st)))
+            out.append((f"rowbias+res {m}x{n}", dict(a=a, w=w, rowbias=rb, rows_per_group=rpg, residual=res)))
+        if n == 2560:
+            out.append((f"geglu LN inline {m}x{n}", dict(a=a, w=w, bias=bias, geglu=True, ln=("inline", cs), _ln_ref=st)))
+            out.append((f"geglu bias {m}x{n}", dict(a=a, w=w, bias=bias, geglu=True)))
+        wide = rn(m, 1280).to(dt)
+        out.append((f"strided A/C {m}x{n}", dict(a=wide[:, 320:640], w=w, bias=bias, out=torch.zeros(m, 2 * n, device=dev, dtype=dt)[:, n:])))
+    return out
+
+
+def reference(kw):
+    a = kw["a"].float()
+    dt = kw["a"].dtype
+    if kw.get("ln") is not None:
+        st = kw["ln"][0]
+        if isinstance(st, str):
+            st = kw["_ln_ref"]
+        a = (a - st[:, :1]) * st[:, 1:]
+    y = a @ kw["w"].float().t()
+    if kw.get("bias") is not None:
+        y = y + kw["bias"]
+    if kw.get("rowbias") is not None:
+        y = y + kw["rowbias"].repeat_interleave(kw["rows_per_group"], 0)[: y.shape[0]]
+    y = y.to(dt).float()
+    if kw.get("residual") is not None:
+        y = y + kw["residual"].float()
+    if kw.get("geglu"):
+        y = y[:, 0::2] * F.gelu(y[:, 1::2])
+    return y
+
+
+def call(kw, frag):
+    kw = {k: v for k, v in kw.items() if not k.startswith("_")}
+    if kw.get("ln") is not None and isinstance(kw["ln"][0], str):
+        kw["ln"] = (K.RowStats(kw["a"], 1e-5), kw["ln"][1])
+    w = kw["w"]
+    if hasattr(w, "_frag"):
+        del w._frag
+    if frag:
+        K.attach_w_frag(w, bool(kw.get("geglu")))
+    if kw.get("out") is not None:
+        kw["out"].zero_()
+    return K.gemm(**kw)
+
+
+def check():
+    bad = 0
+    for dt in (torch.float16, torch.bfloat16):
+        for name, kw in cases(dt):
+            lab = label(lambda: call(kw, True))
+            outs = [call(kw, True).clone() for _ in range(3)]
+            old = call(kw, False).clone()
+            lab_old = label(lambda: call(kw, False))
+            ref = reference(kw)
+            rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
+            rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+            same = all(torch.equal(outs[0], o) for o in outs[1:])
+            nd = (outs[0] != old).float().mean().item()
+            tol = 2e-3 if dt == torch.float16 else 1.2e-2
+            ok = rel < tol and same and torch.isfinite(outs[0].float()).all() and (lab == "ar128x64" or (lab == "wres160" and kw["w"].shape[0] < 960))
+            bad += not ok
+            print(f"{str(dt)[6:]:9s} {name:36s} {lab:9s} rel {rel:.2e} (was {lab_old} {rel_old:.2e}) differing elements {nd:.2e} deterministic={same}{'' if ok else '   <<<<<< FAIL'}", flush=True)
+    return bad
+
+
+def timeit(fn, it=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(it):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / it * 1e3
+
+
+def timing():
+    dt = torch.float16
+    for (m, n, extra) in [(131072, 2560, "geglu+ln"), (131072, 960, "ln"), (131072, 960, "ln+rb"), (131072, 1280, ""), (131072, 320, "res"), (131072, 320, ""), (131072, 320, "ln"),
+                          (196608, 2560, "geglu+ln"), (196608, 960, "ln")]:
+        a = torch.randn(m, 320, device=dev).to(dt)
+        w = (torch.randn(n, 320, device=dev) * 320 ** -0.5).to(dt)
+        bias, res = torch.randn(n, device=dev), torch.randn(m, n, device=dev).to(dt)
+        cs = w.float().sum(1).contiguous()
+        kw = dict(a=a, w=w, bias=bias)
+        if "res" in extra:
+            kw["residual"] = res
+        if "geglu" in extra:
+            kw["geglu"] = True
+        if "ln" in extra:
+            kw["ln"] = ("inline", cs)
+        if "rb" in extra:
+            kw["rowbias"], kw["rows_per_group"] = torch.randn(m // 4096, n, device=dev), 4096
+        row = []
+        for frag in (True, False, True, False):
+            lab = label(lambda: call(kw, frag))
+            kk = {k: v for k, v in kw.items()}
+            if kk.get("ln") is not None:
+                kk["ln"] = (K.RowStats(a, 1e-5), cs)
+            row.append((lab, timeit(lambda: K.gemm(**kk))))
+        fl = 2 * m * n * 320
+        print(f"time {m}x{n}x320 {extra:9s} " + "  ".join(f"{lab} {us:7.1f} us {fl / us * 1e-6:6.1f} TF" for lab, us in row), flush=True)
+
+
+if __name__ == "__main__":
+    rc = 0
+    if "--time-only" not in sys.argv:
+        rc = check()
+    timing()
+    sys.exit(1 if rc else 0)
