@@ -96,6 +96,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
   int fa_b[2][2] = {{fa_lane, fa_lane ^ 64}, {fa_lane + 4 * 16 * ROWB, (fa_lane ^ 64) + 4 * 16 * ROWB}};
   asm volatile("" : "+v"(fa_b[0][0]), "+v"(fa_b[0][1]), "+v"(fa_b[1][0]), "+v"(fa_b[1][1]));
 
+  // The two blocks of a CU start together and have the same timeline: left alone their waves share the matrix pipe during both
+  // K loops and the VALU during both epilogues -- lock-step, neutrally stable -- and nothing overlaps.  The second round of blocks
+  // (the ones that land beside a resident block) therefore starts half an item late: one block's epilogue then runs beside the
+  // other's K loop, and the offset persists across tiles.
+  if (p.dbg >= 3 && blockIdx.x >= gridDim.x / 2) {
+    for (int i = 0; i < p.dbg; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles each
+  }
   for (int tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
     const int m0 = tile * BM;
     __syncthreads();  // every wave has finished its reads of the previous tile
@@ -144,11 +151,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
     // item q of a tile = panel (q + tile) mod panels (the blocks of a round do not all pull the same W panel at the same time);
     // wave w takes items w, w + 4, ...
     auto panel_of = [&](int q) __attribute__((always_inline)) -> int { return (q + tile) % panels; };
-    u32x4 fa[TM], fb[TN];
+    // W fragments two chunks ahead (fb[chunk & 1]): one chunk (24 MFMAs, ~500 cycles) does not cover an L2 round trip when every
+    // CU streams W (measured: 131072x2560x320 GEGLU 292 us with one chunk of lead)
+    u32x4 fa[TM], fb[2][TN];
     {
       const unsigned wb0 = (unsigned)panel_of(wid) * (unsigned)(KQ * TN * 1024);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, wb0 + (unsigned)j * 1024u, 0));
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, wb0 + (unsigned)(c * TN + j) * 1024u, 0));
     }
     for (int q = wid; q < panels; q += 4) {
       const int pn = panel_of(q);
@@ -169,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            if (kq == 0) acc[i][j] = Elem<DT>::mfma(fb[j], fa[i], (f32x4){0.f, 0.f, 0.f, 0.f});
-            else acc[i][j] = Elem<DT>::mfma(fb[j], fa[i], acc[i][j]);
+            if (kq == 0) acc[i][j] = Elem<DT>::mfma(fb[0][j], fa[i], (f32x4){0.f, 0.f, 0.f, 0.f});
+            else acc[i][j] = Elem<DT>::mfma(fb[kq & 1][j], fa[i], acc[i][j]);
             if (j == TN - 1 && nk < KQ) {
               // the next chunk's A fragment i replaces this one right behind its last MFMA
               __builtin_amdgcn_sched_barrier(0);
@@ -180,8 +191,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
           }
           __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
-          // ... and the next chunk's W fragment j behind the eight MFMAs of column tile j (it is needed 24 MFMAs later)
-          if (nk < KQ) fb[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, wbase + (unsigned)((nk * TN + j) * 1024), 0));
+          // ... and W fragment j of the chunk after the next behind the eight MFMAs of column tile j (needed 56 MFMAs later)
+          if (kq + 2 < KQ) fb[kq & 1][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, wbase + (unsigned)(((kq + 2) * TN + j) * 1024), 0));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -197,7 +208,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
       if (q + 4 < panels) {
         const unsigned wb1 = (unsigned)panel_of(q + 4) * (unsigned)(KQ * TN * 1024);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, wb1 + (unsigned)j * 1024u, 0));
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, wb1 + (unsigned)(c * TN + j) * 1024u, 0));
       }
       f32x4 bi[TN], cs[TN];
       const unsigned rb_off = (unsigned)(m0 / p.rows_per_group) * (unsigned)p.ld_rowbias * 4u;  // (rows_per_group % 128 == 0: one group per tile)
@@ -213,14 +226,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
       }
       // (statistics possibly this block's own stores of a moment ago: written through to L2 and awaited before the barrier; the
       //  vector L1 cannot hold an older copy -- a tile's 1 KB of statistics is touched by this block only, after the write)
-      float2 st[TM];
+      auto st_load = [&](int i) __attribute__((always_inline)) -> u32x2 {
+        const int m = m0 + i * 16 + l15;
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_st, m < p.m ? (unsigned)m * 8u : OOB_V, 0, 0));
+      };
+      u32x2 st_nx[2] = {(u32x2){0u, 0u}, (u32x2){0u, 0u}};  // two rows ahead
       if (EPI != 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int m = m0 + i * 16 + l15;
-          const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_st, m < p.m ? (unsigned)m * 8u : OOB_V, 0, 0));
-          st[i] = make_float2(__uint_as_float(t[0]), __uint_as_float(t[1]) + rstd_id);
-        }
+        st_nx[0] = st_load(0);
+        st_nx[1] = st_load(1);
       }
       constexpr int WR = geglu ? 4 : 8;  // packed registers per row: 32 outputs / 64 outputs
       unsigned w[TM][WR];
@@ -236,6 +249,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if (EPI == 0 && i + 1 < TM) res_load(i + 1);
+        const float2 st = make_float2(__uint_as_float(st_nx[i & 1][0]), __uint_as_float(st_nx[i & 1][1]) + rstd_id);
+        if (EPI != 0 && i + 2 < TM) st_nx[i & 1] = st_load(i + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float x = acc[i][j][r];
-            if (EPI != 0) x = st[i].y * (x - st[i].x * cs[j][r]);
+            if (EPI != 0) x = st.y * (x - st.x * cs[j][r]);
             v[r] = x + bi[j][r];
           }
           if (EPI == 2) {
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = m0 + i * 16 + l15;
-        const unsigned ro = m < p.m ? (unsigned)m * (unsigned)p.ldc * 2u + (unsigned)(geglu ? (n0 >> 1) : n0) * 2u : OOB_V;
+        const unsigned ro = (m < p.m && p.dbg != 1) ? (unsigned)m * (unsigned)p.ldc * 2u + (unsigned)(geglu ? (n0 >> 1) : n0) * 2u : OOB_V;  // (dbg 1: timing without stores)
         __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][0], w[i][1], w[i][2], w[i][3]}, rs_c, ro + (unsigned)(8 * g) * 2u, 0, 0);
         if (EPI != 2) __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][4], w[i][5], w[i][6], w[i][7]}, rs_c, ro + (unsigned)(32 + 8 * g) * 2u, 0, 0);
       }

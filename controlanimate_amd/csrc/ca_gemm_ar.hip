@@ -31,7 +31,10 @@ int launch_ar(const GemmKParams& p, hipStream_t st) {
 }
 }  // namespace
 
-int ca_launch_gemm_ar(const ca_gemm_detail::GemmKParams& p, int dtype, hipStream_t st) {
+int ca_launch_gemm_ar(const ca_gemm_detail::GemmKParams& p0, int dtype, hipStream_t st) {
+  static const int dbg = CA_KNOB("CA_PP_DBG", 0);  // (timing experiments: 1 = no stores)
+  ca_gemm_detail::GemmKParams p = p0;
+  p.dbg = dbg;
   return dtype == CA_BF16 ? launch_ar<CA_BF16>(p, st) : launch_ar<CA_F16>(p, st);
 }
 

@@ -10,6 +10,8 @@ broadcast) laid out as the kernels want it:
   * fused projections:  q|k|v (self-attention) and k|v (cross-attention) concatenated along N
   * GEGLU:              rows interleaved (h0, g0, h1, g1, ...) so the gate sits next to its value
   * biases, norm affine parameters, positional tables: fp32
+  * K = 320 projections with N >= 960 (q|k|v, GEGLU of the 64x64-latent level): a second copy in MFMA-fragment order
+    (`frag_order`, = ca_pack_w_frag) for the activation-resident kernel, whose waves read W fragments straight from L2
 """
 from __future__ import annotations
 
@@ -26,7 +28,7 @@ ALIGN = 256  # bytes
 class Packed:
     """Handle to one packed tensor inside the arena (valid after WeightArena.finalize)."""
 
-    __slots__ = ("shape", "dtype", "fill", "offset", "t")
+    __slots__ = ("shape", "dtype", "fill", "offset", "t", "frag")
 
     def __init__(self, shape, dtype, fill):
         self.shape = tuple(int(s) for s in shape)
@@ -34,6 +36,7 @@ class Packed:
         self.fill = fill
         self.offset = -1
         self.t: Optional[torch.Tensor] = None
+        self.frag = None  # (Packed, geglu): the fragment-ordered twin of this weight (ca_gemm_args.w_frag), linked in finalize
 
     @property
     def nbytes(self) -> int:
@@ -66,6 +69,9 @@ class WeightArena:
             view.copy_(src.to(device=device, dtype=p.dtype, non_blocking=False))
             p.t = view
             p.fill = None
+        for p in self.items:
+            if p.frag is not None:  # kernels.gemm hands the twin over with the weight
+                p.t._frag = (p.frag[0].t, bool(p.frag[1]))
         return self.buffer
 
     @property
@@ -75,6 +81,25 @@ class WeightArena:
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
     return t.detach().float()
+
+
+def frag_order(w: torch.Tensor, geglu: bool) -> torch.Tensor:
+    """[N, 320] -> the same elements in the order ca_gemm_args.w_frag takes (= ca_pack_w_frag, csrc/ca_gemm_ar.h): 16-byte piece
+    L (64 per MFMA tile) of tile j (4 per 64-column panel) of 32-deep chunk kq (10) of panel pn holds
+    W[pn * 64 + col(j, L & 15)][kq * 32 + (L >> 4) * 8 : + 8], col = the weight-row interleave behind the 16-byte stores."""
+    n, k = w.shape
+    assert k == 320 and n % 64 == 0
+    j = torch.arange(4).view(4, 1)
+    i = torch.arange(16).view(1, 16)
+    col = (16 * (i >> 2) + 4 * j + (i & 3)) if geglu else (32 * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3))  # [j, i]
+    rows = (torch.arange(n // 64).view(-1, 1, 1) * 64 + col.view(1, 4, 16)).to(w.device)                           # [pn, j, i]
+    x = w[rows.reshape(-1)].view(n // 64, 4, 16, 10, 4, 8)  # [pn, j, i = L & 15, kq, g = L >> 4, e]
+    return x.permute(0, 3, 1, 4, 2, 5).reshape(n, k).contiguous()  # [pn, kq, j, g, i, e]
+
+
+def frag_wanted(n: int, k: int) -> bool:
+    """The shapes the activation-resident kernel takes (ca_gemm.hip ar_eligible): K = 320, N a multiple of 320, N >= 960."""
+    return k == 320 and n % 320 == 0 and n >= 960
 
 
 class HipLinear(nn.Module):
@@ -219,6 +244,8 @@ class LnFold:
             return geglu_interleave(b) if geglu else b
 
         self.w = arena.add((n, k), dtype, w_fold)
+        if frag_wanted(n, k):
+            self.w.frag = (arena.add((n, k), dtype, lambda: frag_order(w_fold(), geglu)), geglu)
         self.cs = arena.add((n,), torch.float32, lambda: w_fold().to(dtype).float().sum(1))
         self.b = arena.add((n,), torch.float32, bias)
         self.pe = None

@@ -22,7 +22,7 @@ def capi():
 FAKE = 0x10000  # never dereferenced: the plan only looks at sizes, flags and which pointers are set
 
 
-def gemm_label(capi, m, n, k, *, geglu=0, res=False, ln=None, row_sums=False, workspace=False, k2=0):
+def gemm_label(capi, m, n, k, *, geglu=0, res=False, ln=None, row_sums=False, workspace=False, k2=0, frag=False, rowbias=0):
     a = capi.GemmArgs(a=FAKE, w=FAKE, c=FAKE, m=m, n=n, k1=k - k2, k2=k2, lda=k - k2, lda2=k2, ldc=n // 2 if geglu else n,
                       alpha=1.0, post_scale=1.0, dtype=capi.CA_F16, geglu=geglu, rows_per_group=1)
     if k2:
@@ -39,6 +39,10 @@ def gemm_label(capi, m, n, k, *, geglu=0, res=False, ln=None, row_sums=False, wo
         a.row_sums_out = FAKE
     if workspace:
         a.workspace, a.workspace_bytes = FAKE, 1 << 40
+    if frag:  # the fragment-ordered twin of W (ABI v9): layers.LnFold packs one for K = 320, N >= 960
+        a.w_frag = FAKE
+    if rowbias:
+        a.rowbias, a.rows_per_group, a.ld_rowbias = FAKE, rowbias, n
     buf = C.create_string_buffer(64)
     rc = capi.lib().ca_gemm_plan_name(C.byref(a), buf, 64)
     assert rc == 0, capi.lib().ca_last_error()
@@ -61,12 +65,18 @@ def conv_label(capi, images, h, cin, cout, *, cin2=0, stride=1, upsample=0, work
 # (M, N, K, keyword flags) -> label.  Rows = the dense launches of one config-2 denoise step (ControlNet + UNet3D,
 # `bench.py --shapes`), largest time share first.  Labels: wres160 = weight-resident K = 320 kernel, ps128x320 = persistent
 # streaming kernel (round 3), pq256x320 = its 256 x 320 / 128 x 80-wave-tile sibling (round 3), pp128x320 = ping-pong 128 x 320 tiles, BMxBN = k_gemm_dma tiles (_db: two LDS stages),
-# _splitkS = S K ranges + reduce, reg_ = register-staged fallback.
+# _splitkS = S K ranges + reduce, reg_ = register-staged fallback, ar128x64 = activation-resident K = 320 kernel (round 4: the launches
+# that hand over W in fragment order and, for in-kernel LayerNorm statistics, the 8 M bytes of scratch -- what kernels.gemm does).
 GEMMS = [
-    ((131072, 2560, 320, dict(geglu=1, ln="inline")), "wres160"),     # FF projection + GEGLU, 64x64 latents
+    ((131072, 2560, 320, dict(geglu=1, ln="inline", frag=True, workspace=True)), "ar128x64"),  # FF projection + GEGLU, 64x64 latents
     ((131072, 320, 320, dict(res=True)), "wres160"),                  # to_out / proj_out (+ residual)
     ((131072, 320, 320, dict()), "wres160"),                          # proj_in, to_q (cross)
-    ((131072, 960, 320, dict(ln="inline")), "wres160"),               # q|k|v
+    ((131072, 960, 320, dict(ln="inline", frag=True, workspace=True)), "ar128x64"),            # q|k|v
+    ((131072, 960, 320, dict(ln="inline", frag=True, workspace=True, rowbias=4096)), "ar128x64"),  # temporal q|k|v (+ pe W^T per frame)
+    ((131072, 2560, 320, dict(geglu=1, ln="inline")), "wres160"),     # without the fragment-ordered weights: the weight-resident kernel
+    ((131072, 960, 320, dict(ln="inline", frag=True)), "wres160"),    # without the statistics scratch: likewise
+    ((131072, 960, 320, dict(ln="inline")), "wres160"),
+    ((131072, 320, 320, dict(res=True, frag=True)), "wres160"),       # N = 320: five 64-column panels for four waves -- stays
     ((32768, 5120, 640, dict(geglu=1, ln=2)), "ps128x320"),
     ((32768, 640, 640, dict(res=True, row_sums=True)), "pq256x320"),    # (ABI v8: row sums per wave quarter, finished by ca_ln_finish_sums)
     ((32768, 640, 640, dict()), "pq256x320"),
@@ -160,3 +170,27 @@ def test_consumer_of_partial_sums_is_told_when_finished_statistics_are_better(ca
     assert wants(8192, 3840, 1280, 4) == 0          # keeps the 128 x 128 kernel, which finishes the sums itself
     assert wants(32768, 1920, 640, 0) == 0          # already finished
     assert wants(131072, 960, 320, 1) == 0          # K = 320: weight-resident / streaming kernels
+
+
+def test_activation_resident_kernel_only_takes_what_it_implements(capi):
+    """ABI v9: w_frag selects the activation-resident kernel for K = 320, M >= 16384, N % 320 == 0, N >= 960, plain epilogues;
+    everything else keeps its old plan, and the statistics scratch is what ca_gemm_workspace_bytes asks for."""
+    lib = capi.lib()
+    assert gemm_label(capi, 131072, 1280, 320, frag=True) == "ar128x64"
+    assert gemm_label(capi, 131072, 960, 320, ln="stats", frag=True) == "ar128x64"           # finished statistics: no scratch needed
+    assert gemm_label(capi, 8192, 960, 320, ln="stats", frag=True) != "ar128x64"             # M < 16384
+    assert gemm_label(capi, 131072, 960, 640, frag=True, k2=320) != "ar128x64"               # two sources / K = 640
+    assert gemm_label(capi, 131072, 960, 320, ln="stats", res=True, frag=True) == "wres160"  # LayerNorm + residual: not implemented there
+    assert gemm_label(capi, 131072, 960, 320, frag=True, rowbias=4032) == "wres160"          # row-bias groups must be whole 128-row tiles
+    assert gemm_label(capi, 131072, 960, 320, ln=1, frag=True) == "ps128x320"                # partial sums: the kernels that finish them
+    a = capi.GemmArgs(a=FAKE, w=FAKE, c=FAKE, m=131072, n=960, k1=320, lda=320, ldc=960, alpha=1.0, post_scale=1.0, dtype=capi.CA_F16,
+                      rows_per_group=1, ln_colsum=FAKE, ln_eps=1e-5, w_frag=FAKE)
+    assert lib.ca_gemm_workspace_bytes(C.byref(a)) == 131072 * 8
+    assert lib.ca_gemm_ln_inline_supported(C.byref(a)) == 1
+    a.w_frag = None
+    assert lib.ca_gemm_workspace_bytes(C.byref(a)) == 0
+    a.w_frag, a.alpha = FAKE, 0.5
+    assert lib.ca_gemm_workspace_bytes(C.byref(a)) == 0  # (alpha != 1: the weight-resident kernel keeps the launch)
+    # ca_pack_w_frag argument checks
+    for args in ((None, 960, 320, 0, FAKE), (FAKE, 960, 640, 0, FAKE), (FAKE, 100, 320, 0, FAKE), (FAKE, 960, 320, 0, 0x10008)):
+        assert lib.ca_pack_w_frag(args[0], args[1], args[2], args[3], args[4], None) < 0 and b"ca_pack_w_frag" in lib.ca_last_error()

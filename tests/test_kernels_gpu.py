@@ -572,6 +572,40 @@ def test_gemm_weight_resident_k320(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_activation_resident_k320(dtype):
+    """The activation-resident kernel (ca_gemm_ar.h, ABI v9: `w_frag`): q|k|v and GEGLU projections of the 64x64-latent level.
+    Every epilogue it implements (bias, residual, row bias per frame, folded LayerNorm with finished or in-kernel statistics,
+    GEGLU), ragged M (a last tile of 8 / 72 rows), strided A / C -- each against an fp32 reference, bit-for-bit repeatable,
+    dispatched to the kernel this test is about, and the same call WITHOUT the fragment-ordered weights (the weight-resident
+    kernel) within rounding of it.  ca_pack_w_frag == layers.frag_order (what the arena holds)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ar_check
+    from controlanimate_amd.layers import frag_order
+    k = _k()
+    tol = 2e-3 if dtype == torch.float16 else 1.2e-2
+    for name, kw in ar_check.cases(dtype, small=True):
+        lab = ar_check.label(lambda: ar_check.call(kw, True))
+        assert lab == "ar128x64", (name, lab)
+        outs = [ar_check.call(kw, True).clone() for _ in range(2)]
+        old = ar_check.call(kw, False)
+        ref = ar_check.reference(kw)
+        rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
+        assert torch.isfinite(outs[0].float()).all() and rel < tol, (name, rel)
+        assert torch.equal(outs[0], outs[1]), name
+        assert ((outs[0].float() - old.float()).norm() / ref.norm()).item() < tol / 4, name
+        if "ln" not in kw and not kw.get("geglu"):  # (the statistics' summation order differs between the kernels; GEGLU products a last bit)
+            assert torch.equal(outs[0], old), name
+    for geglu in (False, True):
+        w = rnd(2560, 320, dtype=dtype, seed=11).to(DEV)
+        k.attach_w_frag(w, geglu)
+        assert torch.equal(w._frag[0], frag_order(w, geglu)) and w._frag[1] == geglu
+    # a weight the kernel cannot take gets no twin
+    w = rnd(640, 640, dtype=dtype, seed=12).to(DEV)
+    assert not hasattr(k.attach_w_frag(w), "_frag")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,c", [(8192, 1280), (32768 - 24, 640)])
 def test_layernorm_statistics_handed_from_producer_to_consumer(m, c, dtype):
     """ABI v6 row_sums_out / ln_parts: the GEMM that writes a tensor leaves (sum, sum of squares) of every stored row per

@@ -20,11 +20,12 @@ def label(fn):
         K._plan_sink = None
 
 
-def cases(dt):
+def cases(dt, small=False):
     g = torch.Generator(device="cpu").manual_seed(7)
     rn = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev)
     out = []
-    for (m, n) in [(16384 + 8, 960), (131072, 960), (16384 + 200, 2560), (32768, 1280), (20000, 320)]:
+    for (m, n) in ([(16384 + 8, 960), (20480, 960), (16384 + 200, 2560), (16384, 1280)] if small else
+                   [(16384 + 8, 960), (131072, 960), (16384 + 200, 2560), (32768, 1280), (20000, 320)]):
         k = 320
         a = rn(m, k).to(dt)
         w = rn(n, k, scale=k ** -0.5).to(dt)
