@@ -96,13 +96,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
   int fa_b[2][2] = {{fa_lane, fa_lane ^ 64}, {fa_lane + 4 * 16 * ROWB, (fa_lane ^ 64) + 4 * 16 * ROWB}};
   asm volatile("" : "+v"(fa_b[0][0]), "+v"(fa_b[0][1]), "+v"(fa_b[1][0]), "+v"(fa_b[1][1]));
 
-  // The two blocks of a CU start together and have the same timeline: left alone their waves share the matrix pipe during both
-  // K loops and the VALU during both epilogues -- lock-step, neutrally stable -- and nothing overlaps.  The second round of blocks
-  // (the ones that land beside a resident block) therefore starts half an item late: one block's epilogue then runs beside the
-  // other's K loop, and the offset persists across tiles.
-  if (p.dbg >= 3 && blockIdx.x >= gridDim.x / 2) {
-    for (int i = 0; i < p.dbg; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles each
-  }
   for (int tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
     const int m0 = tile * BM;
     __syncthreads();  // every wave has finished its reads of the previous tile
@@ -262,6 +255,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
             v[r] = x + bi[j][r];
           }
           if (EPI == 2) {
+#ifdef CA_EXPERIMENTS
+            if (p.dbg == 2 || p.dbg == 5) {  // (timing only: no GELU arithmetic)
+              w[i][j] = pack2<DT>(v[0] + v[1], v[2] + v[3]);
+              continue;
+            }
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = Elem<DT>::to_f(Elem<DT>::from_f(v[r]));  // (the Linear's output is rounded first)
             const f32x2 gg = gelu_erf_f2((f32x2){v[1], v[3]});
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = m0 + i * 16 + l15;
-        const unsigned ro = (m < p.m && p.dbg != 1) ? (unsigned)m * (unsigned)p.ldc * 2u + (unsigned)(geglu ? (n0 >> 1) : n0) * 2u : OOB_V;  // (dbg 1: timing without stores)
+        const unsigned ro = (m < p.m && p.dbg != 1 && p.dbg != 5) ? (unsigned)m * (unsigned)p.ldc * 2u + (unsigned)(geglu ? (n0 >> 1) : n0) * 2u : OOB_V;  // (dbg 1: timing without stores)
         __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][0], w[i][1], w[i][2], w[i][3]}, rs_c, ro + (unsigned)(8 * g) * 2u, 0, 0);
         if (EPI != 2) __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][4], w[i][5], w[i][6], w[i][7]}, rs_c, ro + (unsigned)(32 + 8 * g) * 2u, 0, 0);
       }

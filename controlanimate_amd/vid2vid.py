@@ -114,14 +114,24 @@ def match_colors(frames: Sequence, ref_frame, normalize: bool = True) -> List:
     result in `Normalizer(...).uint8_norm()` (:122, :125, :127) -- min-max normalisations of the `color_matcher`
     package: the transfer therefore targets the CONTRAST-STRETCHED reference frame and its result is stretched to the
     full 0..255 range again (`normalize=True`, the default; `False` = plain /255 and clip, the round-2 behaviour).
-    The package is absent here: this restatement follows its published source and is unpinned against it; the property
-    tests are in tests/test_vid2vid_host.py."""
-    ref = _to_np(ref_frame).astype(np.float64)
-    ref = _minmax(ref) if normalize else ref / 255.0
+    `type_norm` keeps an integer image in its own type: the stretched uint8 frames are ROUNDED before the transfer (round 4:
+    mirrored here; the first restatement kept them in float64).  The package is absent here: this restatement follows its
+    published source and is unpinned against it; the property tests are in tests/test_vid2vid_host.py."""
+    def type_norm(a: np.ndarray) -> np.ndarray:
+        # Normalizer.type_norm(): an INTEGER image (PIL frames are uint8) comes back in its own type -- min-max stretched to the
+        # type's range and ROUNDED, i.e. quantised before the transfer sees it; a float image is stretched to 0..1 unrounded.
+        # (The transfer is scale-equivariant and the result is min-max normalised again, so only the rounding matters.)
+        if not normalize:
+            return a.astype(np.float64) / 255.0
+        if np.issubdtype(a.dtype, np.integer):
+            info = np.iinfo(a.dtype)
+            return np.round(_minmax(a.astype(np.float64)) * (float(info.max) - float(info.min)) + float(info.min))
+        return _minmax(a.astype(np.float64))
+
+    ref = type_norm(_to_np(ref_frame))
     out = []
     for fr in frames:
-        x = _to_np(fr).astype(np.float64)
-        x = _minmax(x) if normalize else x / 255.0
+        x = type_norm(_to_np(fr))
         y = _hist_match(_mkl(_hist_match(x, ref), ref), ref)
         if normalize:
             y = _minmax(y)

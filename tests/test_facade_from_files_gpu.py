@@ -60,6 +60,9 @@ def test_skeleton_rank_receives_the_weights_and_reproduces_the_frames(model_tree
         skel = ControlAnimatePipeline(cfg, skeleton=True)
     finally:
         local_models.read_checkpoint = orig
+    # (the textual-inversion file IS read: its vector count fixes how many tokens the tokenizer and the token table grow by --
+    #  25 KB, and the values are overwritten by the broadcast like everything else)
+    reads = [r for r in reads if "easynegative" not in str(r[0])]
     assert not reads, f"the skeleton read weight files: {reads}"
     assert not local_models.is_skeleton()  # the process-global flag is restored
     bf, bs = full.weight_buffers(), skel.weight_buffers()

@@ -123,6 +123,13 @@ def test_match_colors_hm_mkl_hm_properties():
         assert abs(outn[..., c].mean() - stretched[..., c].mean()) < 2.5
     # (<= 3: the MKL step perturbs equal grey levels by 1e-16, which splits their ties in the second histogram match)
     assert np.abs(match_colors([dim], dim)[0].astype(int) - stretched.astype(int)).max() <= 3
+    # Normalizer.type_norm keeps an integer image in its type: stretched AND rounded before the transfer -- a uint8
+    # frame and the same frame handed over as already-stretched-and-rounded values give the same result; a float frame with the
+    # same values is stretched but not rounded (and may differ by a grey level)
+    pre = np.round((dim.astype(np.float64) - dim.min()) / (float(dim.max()) - float(dim.min())) * 255).astype(np.uint8)
+    assert pre.min() == 0 and pre.max() == 255
+    assert np.array_equal(match_colors([src], dim)[0], match_colors([src], pre)[0])
+    assert np.abs(match_colors([src], dim.astype(np.float32))[0].astype(int) - outn.astype(int)).max() <= 2
     x, y = src.astype(np.float64) / 255, ref.astype(np.float64) / 255
     t = _mkl(x, y).reshape(-1, 3)
     assert np.allclose(np.cov(t, rowvar=False), np.cov(y.reshape(-1, 3), rowvar=False), atol=1e-8)
