@@ -165,6 +165,8 @@ def rocprof_kernel_name(family: str, dtype: str) -> str:
     mode = 1 if op == "conv3x3" else 0
     if tile == "wres160":
         return f"k_gemm_wres<{dt}>"
+    if tile == "ar128x64":  # (every epilogue variant: k_gemm_ar<dt, EPI>)
+        return f"k_gemm_ar<{dt}, "
     if tile.startswith("pp128x320"):
         return f"k_gemm_pp2<{dt}, {mode}"
     if tile == "ps128x320":
@@ -174,7 +176,7 @@ def rocprof_kernel_name(family: str, dtype: str) -> str:
     base = tile.split("_")[0]
     bm, bn = base.split("x")
     waves = "4, 1" if base == "128x64" else "2, 2"
-    nbuf = 2 if tile.endswith("_db") else 1
+    nbuf = 2 if tile.endswith("_db") else 3 if tile.endswith("_r3") else 4 if tile.endswith("_r4") else 1
     return f"k_gemm_dma<{dt}, {bm}, {bn}, {waves}, {mode}, {nbuf}, "
 
 
@@ -182,6 +184,8 @@ def kernel_display_name(family: str) -> str:
     tile = family.split("_", 1)[1]
     if tile == "wres160":
         return f"k_gemm_wres<{family}>"
+    if tile == "ar128x64":
+        return f"k_gemm_ar<{family}>"
     if tile.startswith("pp128x320"):
         return f"k_gemm_pp2<{family}>"
     if tile == "ps128x320":
@@ -191,7 +195,7 @@ def kernel_display_name(family: str) -> str:
     return f"k_gemm_dma<{family}>"
 
 
-PMC_SUMMARIES = ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
+PMC_SUMMARIES = ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
 
 
 def pmc_traffic(kernel_prefix: str, workload_key: str, dtype: str):

@@ -167,13 +167,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmKParams p) {
 
 // NBUF = 2: tile t+1 is issued before the MFMA phase of tile t, `__syncthreads()` (which hipcc
 //           precedes with vmcnt(0)) once per tile.
-// NBUF = 3: tiles are issued TWO ahead into a 3-slot ring; a wave waits with a COUNTED
-//           `s_waitcnt vmcnt(per-tile DMA count)` (tile t landed, tile t+1 may still be in flight),
-//           then a raw s_barrier: DMA transfers stay in flight across barriers
+// NBUF >= 3: tiles are issued NBUF - 1 ahead into a ring; a wave waits with a COUNTED
+//           `s_waitcnt vmcnt(per-tile DMA count x younger tiles)` (tile t landed, the younger ones may still be in
+//           flight), then a raw s_barrier: DMA transfers stay in flight across barriers
 //           (cdna_hip_programming.md "Pipelining across barriers").  All LDS is one array.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int NBUF, int KT = 64>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
-                             ((BM / WAVES_M) * (BN / WAVES_N) > 64 * 80 ? 2 : (NBUF * KT == 64 ? (BN > 128 ? 3 : 4) : 2)) * 4 / (WAVES_M * WAVES_N))
+                             ((BM / WAVES_M) * (BN / WAVES_N) > 64 * 80 ? 2 : (NBUF * KT == 64 ? (BN > 128 ? 3 : 4) : (NBUF * (BM + BN) * KT * 2 > 80 * 1024 ? 1 : 2))) * 4 / (WAVES_M * WAVES_N))
 void k_gemm_dma(GemmKParams p) {
   // KT = K elements per LDS stage: 64 (one 128-byte row per tile row) or 32 with NBUF = 2 -- the same 32 KB
   // as one 64-wide stage, so 4 blocks still share a CU, but each block also prefetches its own next stage
@@ -344,6 +344,32 @@ void k_gemm_dma(GemmKParams p) {
       compute(buf);
       __syncthreads();
     }
+  } else {
+    // NBUF >= 3 (round 4): a ring with NBUF - 1 tiles in flight, for the launches whose K loop is a chain of DMA round trips with
+    // almost nothing to compute per tile (M = 2048: the 8x8-latent level -- 8 MFMAs per wave and K tile against ~1.2 us per
+    // round trip).  With two stages ONE tile is in flight while the previous one is computed; here tile t is awaited with a
+    // COUNTED vmcnt (the pieces of the min(NBUF - 2, tiles left) younger tiles stay outstanding), one raw barrier per tile
+    // publishes it, and tile t + NBUF - 1 goes into the slot whose reads the same barrier has just retired.
+    constexpr int PER = AG + BG;  // DMA instructions per wave and stage
+    static_assert((NBUF - 2) * PER < 64, "vmcnt");
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+      if (s < nt) stage(t_first + s, s);
+    int slot = 0, slot_in = NBUF - 1;
+    for (int t = 0; t < nt; ++t) {
+      const int younger = nt - 1 - t < NBUF - 2 ? nt - 1 - t : NBUF - 2;
+      if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PER < 64 ? (NBUF - 2) * PER : 0) : "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + NBUF - 1 < nt) stage(t_first + t + NBUF - 1, slot_in);
+      compute(slot);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this tile's fragment reads have returned before the next barrier lets its slot go)
+      slot = slot + 1 == NBUF ? 0 : slot + 1;
+      slot_in = slot_in + 1 == NBUF ? 0 : slot_in + 1;
+    }
+    __syncthreads();  // the staged epilogue re-uses the ring's LDS
   }
   if (p.splits > 1) {  // raw fp32 slab; lane holds C[m = .. + l15][n = .. + 4g + (0..3)]
     float* slab = p.partial + (int64_t)split * p.m * p.n;
@@ -652,8 +678,13 @@ inline GemmPlan plan_gemm(const GemmKParams& p, int mode, bool allow_pq = true) 
   // and far better than 3-4 stage rings (1 block per CU).  Small grids (< 2 blocks per CU) have no
   // co-resident blocks to overlap with and keep the double buffer.
   static const int nbuf_env = CA_KNOB("CA_GEMM_NBUF", 0);
-  int nbuf = nbuf_env ? nbuf_env : (blocks >= 512 ? 1 : 2);
-  if (nbuf < 1 || nbuf > 2) nbuf = 2;
+  // (round 4: three stages instead of two for the small grids -- their K loops are chains of DMA round trips with 8 MFMAs per
+  //  wave and tile in between; two tiles in flight instead of one: -0.3 ms per step, 62.0 vs 62.3 interleaved three times.  The
+  //  128 x 64 tile's ring is 74 KB: two blocks still share a CU.  Four stages (98 KB, one block per CU) lose.)
+  int nbuf = nbuf_env ? nbuf_env : (blocks >= 512 ? 1 : 3);
+  if (nbuf < 1 || nbuf > 4) nbuf = 3;
+  static const int ring_env = CA_KNOB("CA_GEMM_RING", 0);  // (experiment builds: 2 = the round-3 double buffer, 4 = four stages, for the launches that take the ring)
+  if (nbuf == 3 && (ring_env == 2 || ring_env == 4)) nbuf = ring_env;
   // N = 320 / 960 (every projection and conv of the 64x64-latent level): 128x160 tiles divide N
   // exactly and read the A panel 2 / 6 times instead of 5 / 15 times
   static const int t160_env = CA_KNOB("CA_GEMM_T160", 1);
@@ -709,7 +740,7 @@ inline void plan_label(const GemmPlan& g, char* buf, int len) {
     case PK_PS: snprintf(buf, len, "ps128x320"); break;
     case PK_PQ: snprintf(buf, len, "pq256x320"); break;
     case PK_PP2_SPLITK: snprintf(buf, len, "pp128x320_splitk%d", g.splits); break;
-    case PK_DMA: snprintf(buf, len, "%dx%d%s", g.bm, g.bn, g.nbuf == 2 ? "_db" : ""); break;
+    case PK_DMA: snprintf(buf, len, "%dx%d%s", g.bm, g.bn, g.nbuf == 2 ? "_db" : g.nbuf == 3 ? "_r3" : g.nbuf == 4 ? "_r4" : ""); break;
     case PK_DMA_SPLITK: snprintf(buf, len, "128x128_splitk%d", g.splits); break;
     case PK_REG: snprintf(buf, len, "reg_%dx%d", g.bm, g.bn); break;
     default: snprintf(buf, len, "exp%d", g.exp); break;
@@ -740,7 +771,11 @@ int launch_gemm(const GemmKParams& p, hipStream_t st) {
     case PK_DMA:
       if (g.bn == 160) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 160, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
       else if (g.bn == 128 && g.nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, st, p);
+      else if (g.bn == 128 && g.nbuf == 4) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 4>), grid, dim3(256), 0, st, p);
+      else if (g.bn == 128 && g.nbuf == 3) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 3>), grid, dim3(256), 0, st, p);
       else if (g.bn == 128) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 128, 2, 2, MODE, 2>), grid, dim3(256), 0, st, p);
+      else if (g.bn == 64 && g.nbuf == 4) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 4>), grid, dim3(256), 0, st, p);
+      else if (g.bn == 64 && g.nbuf == 3) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 3>), grid, dim3(256), 0, st, p);
       else if (g.nbuf == 1) hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 1>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((k_gemm_dma<DT, 128, 64, 4, 1, MODE, 2>), grid, dim3(256), 0, st, p);
       return CA_OK;

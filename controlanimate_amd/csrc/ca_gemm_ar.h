@@ -96,7 +96,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ar(GemmKParams p, const u16* __
   int fa_b[2][2] = {{fa_lane, fa_lane ^ 64}, {fa_lane + 4 * 16 * ROWB, (fa_lane ^ 64) + 4 * 16 * ROWB}};
   asm volatile("" : "+v"(fa_b[0][0]), "+v"(fa_b[0][1]), "+v"(fa_b[1][0]), "+v"(fa_b[1][1]));
 
-  for (int tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
+  for (int tile_i = blockIdx.x; tile_i < tiles_m; tile_i += gridDim.x) {
+#ifdef CA_EXPERIMENTS
+    const int tile = p.dbg == 7 ? tiles_m - 1 - tile_i : tile_i;  // (experiment: rows last to first -- what the memory-side cache keeps of the output)
+#else
+    const int tile = tile_i;
+#endif
     const int m0 = tile * BM;
     __syncthreads();  // every wave has finished its reads of the previous tile
     {

@@ -64,7 +64,7 @@ def conv_label(capi, images, h, cin, cout, *, cin2=0, stride=1, upsample=0, work
 
 # (M, N, K, keyword flags) -> label.  Rows = the dense launches of one config-2 denoise step (ControlNet + UNet3D,
 # `bench.py --shapes`), largest time share first.  Labels: wres160 = weight-resident K = 320 kernel, ps128x320 = persistent
-# streaming kernel (round 3), pq256x320 = its 256 x 320 / 128 x 80-wave-tile sibling (round 3), pp128x320 = ping-pong 128 x 320 tiles, BMxBN = k_gemm_dma tiles (_db: two LDS stages),
+# streaming kernel (round 3), pq256x320 = its 256 x 320 / 128 x 80-wave-tile sibling (round 3), pp128x320 = ping-pong 128 x 320 tiles, BMxBN = k_gemm_dma tiles (_r3: a three-stage LDS ring, round 4; _db: two stages),
 # _splitkS = S K ranges + reduce, reg_ = register-staged fallback, ar128x64 = activation-resident K = 320 kernel (round 4: the launches
 # that hand over W in fragment order and, for in-kernel LayerNorm statistics, the 8 M bytes of scratch -- what kernels.gemm does).
 GEMMS = [
@@ -87,13 +87,13 @@ GEMMS = [
     ((131072, 320, 1280, dict(res=True)), "pq256x320"),               # FF out, 64x64 latents
     ((32768, 640, 2560, dict(res=True)), "pq256x320"),
     ((8192, 1280, 5120, dict(res=True)), "pp128x320"),
-    ((2048, 1280, 1280, dict(res=True)), "128x64_db"),
+    ((2048, 1280, 1280, dict(res=True)), "128x64_r3"),
     ((2048, 1280, 5120, dict(res=True, workspace=True)), "pp128x320_splitk4"),
-    ((2048, 1280, 5120, dict(res=True)), "128x64_db"),                # no scratch handed over: unsplit
+    ((2048, 1280, 5120, dict(res=True)), "128x64_r3"),                # no scratch handed over: unsplit
     ((2048, 3840, 1280, dict(ln="stats")), "pp128x320"),
     ((2048, 10240, 1280, dict(geglu=1, ln="stats")), "pq256x320"),
     ((131072, 320, 640, dict(k2=320)), "ps128x320"),                  # shortcut over the skip concat (K = 320 + 320)
-    ((32, 1280, 320, dict()), "128x64_db"),                           # time embedding
+    ((32, 1280, 320, dict()), "128x64_r3"),                           # time embedding
     ((32768, 640, 640, dict(row_sums=True)), "pq256x320"),
     # folded LayerNorm with FINISHED statistics (what kernels.gemm hands over after ca_gemm_wants_finished_stats): 256 x 320 tiles
     ((32768, 5120, 640, dict(geglu=1, ln="stats")), "pq256x320"),
@@ -109,7 +109,7 @@ CONVS = [
     ((32, 16, 1280, 1280, dict()), "pp128x320"),
     ((32, 32, 640, 640, dict()), "pq256x320"),
     ((32, 8, 1280, 1280, dict()), "128x128_splitk6"),
-    ((32, 8, 1280, 1280, dict(workspace=False)), "128x64_db"),
+    ((32, 8, 1280, 1280, dict(workspace=False)), "128x64_r3"),
     ((32, 16, 2560, 1280, dict(cin2=1280)), "pp128x320"),
     ((32, 64, 640, 320, dict(cin2=320)), "pq256x320"),
     ((32, 64, 640, 640, dict(upsample=0)), "pq256x320"),
@@ -140,7 +140,7 @@ def test_partial_layernorm_sums_never_reach_a_kernel_that_reads_mean_rstd(capi):
     reduce kernel and the weight-resident kernel read ln_stats as (mean, rstd): such a launch must take neither."""
     lib = capi.lib()
     # the shape that would split (2048 x 1280 x 5120 with scratch) stays unsplit with ln_parts
-    assert gemm_label(capi, 2048, 1280, 5120, ln=4, workspace=True) == "128x64_db"
+    assert gemm_label(capi, 2048, 1280, 5120, ln=4, workspace=True) == "128x64_r3"
     assert gemm_label(capi, 2048, 1280, 5120, ln="stats", workspace=True) == "pp128x320_splitk4"
     # the weight-resident shape (K = 320, M >= 16384) goes to a kernel whose epilogue finishes partial sums
     assert gemm_label(capi, 131072, 960, 320, ln=1) == "ps128x320"
