@@ -327,11 +327,13 @@ class KernelTimer:
         return agg
 
 
-def build_models(wl, device, dtype):
+def build_models(wl, device, dtype, rank: int = 0):
+    """rank > 0 (multi-rank runs): DIFFERENT random weights, so that the run only works -- and the arena checksums only agree --
+    because rank 0's arenas really arrive over the broadcast (in a single-process run nothing changes)."""
     from controlanimate_amd.configs import controlnet_config, unet_config
     from controlanimate_amd.controlnet import ControlNetModel
     from controlanimate_amd.unet import UNet3DConditionModel
-    torch.manual_seed(0)
+    torch.manual_seed(1000 * rank)
     with torch.device(device):
         unet = UNet3DConditionModel.from_config(unet_config(wl["version"]))
         nets = [ControlNetModel.from_config(controlnet_config()) for _ in range(wl["controlnets"])]
@@ -574,8 +576,15 @@ def main():
     timer = KernelTimer()
     if not args.no_roofline:
         timer.install()
-    unet, nets = build_models(wl, device, dtype)
-    bytes_bcast = WS.broadcast_weights([unet.arena.buffer] + [n.arena.buffer for n in nets])
+    unet, nets = build_models(wl, device, dtype, rank)
+    arenas = [unet.arena.buffer] + [n.arena.buffer for n in nets]
+    bytes_bcast = WS.broadcast_weights(arenas)
+    if world > 1:  # the broadcast is load-bearing (ranks > 0 were built with other weights): every rank must now hold rank 0's bytes
+        chk = torch.stack([a[:: max(1, a.numel() // (1 << 16))].to(torch.int64).sum() for a in arenas])  # (device tensors: RCCL and gloo both take them)
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "ranks disagree on the broadcast weight arenas"
 
     f, lh, lw = wl["frames"], wl["height"] // 8, wl["width"] // 8
     g = torch.Generator().manual_seed(1234)
