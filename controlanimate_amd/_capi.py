@@ -41,6 +41,15 @@ class GemmArgs(C.Structure):
     ]
 
 
+class FfArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w1_frag", C.c_void_p), ("bias1", C.c_void_p), ("colsum1", C.c_void_p), ("ln_stats", C.c_void_p),
+        ("w2_frag", C.c_void_p), ("bias2", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
+        ("lda", C.c_int64), ("ldc", C.c_int64), ("ld_res", C.c_int64),
+        ("m", C.c_int32), ("c", C.c_int32), ("inner", C.c_int32), ("ln_eps", C.c_float), ("dtype", C.c_int32),
+    ]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
@@ -97,6 +106,9 @@ SYMBOLS = {
     "ca_last_error": (C.c_char_p, []),
     "ca_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "ca_pack_w_frag": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ca_pack_w2_frag": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ca_ff_fused": (C.c_int, [C.POINTER(FfArgs), C.c_void_p]),
+    "ca_ff_fused_supported": (C.c_int, [C.POINTER(FfArgs)]),
     "ca_gemm_ln_inline_supported": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_gemm_wants_finished_stats": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_ln_finish_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

@@ -55,10 +55,22 @@ class FeedForward(nn.Module):
         else:
             self.net[0].pack(arena, dtype)
         self.net[2].pack(arena, dtype)
+        # C = 320 (the 64x64-latent level): the output projection once more in the fragment order of the fused feed-forward
+        # kernel (ca_ff_fused: GEGLU projection + output projection in one launch, the [M, 1280] intermediate stays in LDS)
+        self.w2f = None
+        out = self.net[2]
+        if self.fold is not None and self.fold.w.frag is not None and (out.out_features, out.in_features) == (320, 1280):
+            from .layers import frag_order2
+            self.w2f = arena.add((320, 1280), dtype, lambda: frag_order2(out.weight.detach().float()))
 
     def run(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, sums=None) -> torch.Tensor:
         """With a folded LayerNorm `x` is the UN-normalised input (`sums`: row sums its producer left, K.row_sums_of)."""
         fold = getattr(self, "fold", None)
+        if fold is not None and getattr(self, "w2f", None) is not None and sums is None:
+            y = K.ff_fused(x, fold.w.frag[0].t, fold.b.t, fold.cs.t, self.w2f.t, None if self.net[2].b is None else self.net[2].b.t,
+                           fold.eps, residual=residual)
+            if y is not None:
+                return y
         if fold is not None:
             h = K.gemm(x, fold.w.t, bias=fold.b.t, geglu=True, ln=(K.RowStats(x, fold.eps, sums), fold.cs.t))
         else:

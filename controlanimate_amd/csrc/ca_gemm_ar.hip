@@ -4,6 +4,7 @@
 namespace {
 using namespace ca_gemm_detail;
 #include "ca_gemm_ar.h"
+#include "ca_ff_fused.h"
 
 int ar_cu_count() {
   static int n = 0;
@@ -45,5 +46,55 @@ extern "C" int ca_pack_w_frag(const void* w, int32_t n, int32_t k, int32_t geglu
   const int64_t pieces = (int64_t)n * 40;
   hipLaunchKernelGGL(k_pack_w_frag, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16*)w, (u16*)dst, n, geglu);
   CA_CHECK_LAUNCH("ca_pack_w_frag");
+  return CA_OK;
+}
+
+extern "C" int ca_pack_w2_frag(const void* w, int32_t n, int32_t k, void* dst, void* stream) {
+  CA_REQUIRE(w && dst, "ca_pack_w2_frag: null operand");
+  CA_REQUIRE(n == 320 && k == 1280, "ca_pack_w2_frag: n=%d k=%d (320 x 1280)", n, k);
+  CA_REQUIRE((((uintptr_t)w | (uintptr_t)dst) & 15) == 0, "ca_pack_w2_frag: operands must be 16-byte aligned");
+  hipLaunchKernelGGL(k_pack_w2_frag, dim3(200), dim3(256), 0, (hipStream_t)stream, (const u16*)w, (u16*)dst);
+  CA_CHECK_LAUNCH("ca_pack_w2_frag");
+  return CA_OK;
+}
+
+extern "C" int ca_ff_fused_supported(const ca_ff_args* a) {
+  if (!a || !a->x || !a->w1_frag || !a->bias1 || !a->colsum1 || !a->w2_frag || !a->y) return 0;
+  if (a->c != 320 || a->inner != 1280 || a->m < 16384) return 0;
+  if (a->dtype != CA_BF16 && a->dtype != CA_F16) return 0;
+  if (a->lda % 8 || a->ldc % 8 || (a->residual && a->ld_res % 8)) return 0;
+  if ((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->w1_frag | (uintptr_t)a->w2_frag | (uintptr_t)a->residual) & 15) != 0) return 0;
+  const int64_t lim = 0x7FFFFF00ll;
+  if (((int64_t)(a->m - 1) * a->lda + 320) * 2 >= lim || ((int64_t)(a->m - 1) * a->ldc + 320) * 2 >= lim) return 0;
+  if (a->residual && ((int64_t)(a->m - 1) * a->ld_res + 320) * 2 >= lim) return 0;
+  if (!a->ln_stats && !(a->ln_eps > 0.f)) return 0;
+  return 1;
+}
+
+extern "C" int ca_ff_fused(const ca_ff_args* a, void* stream) {
+  CA_REQUIRE(a != nullptr, "ca_ff_fused: null args");
+  CA_REQUIRE(ca_ff_fused_supported(a), "ca_ff_fused: arguments outside what the fused feed-forward takes (C = 320, inner 1280, M >= 16384, fragment-ordered weights, "
+                                        "16-byte aligned operands, 32-bit byte offsets): ask ca_ff_fused_supported() first");
+  FfParams p{};
+  p.x = (const u16*)a->x;
+  p.w1f = (const u16*)a->w1_frag;
+  p.bias1 = a->bias1;
+  p.cs1 = a->colsum1;
+  p.w2f = (const u16*)a->w2_frag;
+  p.bias2 = a->bias2;
+  p.res = (const u16*)a->residual;
+  p.y = (u16*)a->y;
+  p.ln_stats = a->ln_stats;
+  p.lda = a->lda, p.ldc = a->ldc, p.ld_res = a->ld_res;
+  p.m = a->m;
+  p.ln_eps = a->ln_eps;
+  p.x_bytes = (unsigned)(((int64_t)(a->m - 1) * a->lda + 320) * 2);
+  p.y_bytes = (unsigned)(((int64_t)(a->m - 1) * a->ldc + 320) * 2);
+  p.res_bytes = a->residual ? (unsigned)(((int64_t)(a->m - 1) * a->ld_res + 320) * 2) : 0u;
+  const int tiles_m = (a->m + 127) / 128;
+  const unsigned grid = (unsigned)(tiles_m < ar_cu_count() ? tiles_m : ar_cu_count());
+  if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_ff_fused<CA_BF16>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
+  else hipLaunchKernelGGL((k_ff_fused<CA_F16>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
+  CA_CHECK_LAUNCH("ca_ff_fused");
   return CA_OK;
 }

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import (AttnArgs, ConvArgs, GemmArgs, GroupNormArgs, LayerNormArgs, CA_ACT_NONE,
+from ._capi import (AttnArgs, ConvArgs, FfArgs, GemmArgs, GroupNormArgs, LayerNormArgs, CA_ACT_NONE,
                     CA_ACT_SILU, CA_BF16, CA_F16, check, lib)
 
 ACT_NONE, ACT_SILU = CA_ACT_NONE, CA_ACT_SILU
@@ -147,6 +147,33 @@ def attach_w_frag(w: torch.Tensor, geglu: bool = False) -> torch.Tensor:
     check(lib().ca_pack_w_frag(w.data_ptr(), w.shape[0], w.shape[1], int(bool(geglu)), dst.data_ptr(), _stream()), "ca_pack_w_frag")
     w._frag = (dst, bool(geglu))
     return w
+
+
+_FF_FUSED_ON = os.environ.get("CA_FF_FUSED", "1") != "0"  # (0: the feed-forward always as two GEMMs -- A/B runs)
+
+
+def ff_fused(x: torch.Tensor, w1_frag: torch.Tensor, bias1: torch.Tensor, colsum1: torch.Tensor, w2_frag: torch.Tensor,
+             bias2: Optional[torch.Tensor], ln_eps: float, residual: Optional[torch.Tensor] = None,
+             ln_stats: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """y = GEGLU(LN(x) W1^T + b1) W2^T + b2 + residual in one launch (ca_ff_fused, ABI v9: the 64x64-latent level's feed-forward,
+    C = 320) -- or None where the library does not take the arguments (the caller then runs the two GEMMs)."""
+    if not _FF_FUSED_ON:
+        return None
+    _req_cuda(x, w1_frag, bias1, colsum1, w2_frag, bias2, residual, ln_stats)
+    if x.dim() != 2 or x.stride(1) != 1 or (residual is not None and (residual.shape != x.shape or residual.stride(1) != 1 or residual.dtype != x.dtype)):
+        return None
+    m, c = x.shape
+    inner = w2_frag.shape[1]
+    y = torch.empty((m, c), device=x.device, dtype=x.dtype)
+    args = FfArgs(x=_p(x), w1_frag=_p(w1_frag), bias1=_p(bias1), colsum1=_p(colsum1), ln_stats=_p(ln_stats), w2_frag=_p(w2_frag),
+                  bias2=_p(bias2), residual=_p(residual), y=_p(y), lda=x.stride(0), ldc=y.stride(0),
+                  ld_res=residual.stride(0) if residual is not None else 0, m=m, c=c, inner=inner, ln_eps=float(ln_eps), dtype=dt_code(x.dtype))
+    if not lib().ca_ff_fused_supported(C.byref(args)):
+        return None
+    if _plan_sink is not None:
+        _plan_sink.append("ff_fused128")
+    check(lib().ca_ff_fused(C.byref(args), _stream()), "ca_ff_fused")
+    return y
 
 
 _ROW_SUMS_ON = os.environ.get("CA_LN_ROWSUMS", "1") != "0"  # (0: always the separate statistics pass -- A/B runs)

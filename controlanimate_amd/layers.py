@@ -97,6 +97,19 @@ def frag_order(w: torch.Tensor, geglu: bool) -> torch.Tensor:
     return x.permute(0, 3, 1, 4, 2, 5).reshape(n, k).contiguous()  # [pn, kq, j, g, i, e]
 
 
+def frag_order2(w: torch.Tensor) -> torch.Tensor:
+    """[320, 1280] (the feed-forward's output projection at C = 320) -> the order ca_ff_args.w2_frag takes (= ca_pack_w2_frag,
+    csrc/ca_ff_fused.h): 16-byte piece L of MFMA tile j (5 per 80-column range of a consumer wave) of wave wc of h chunk pn
+    (40 chunks of 32) holds W[wc * 80 + col5(j, L & 15)][pn * 32 + (L >> 4) * 8 : + 8]."""
+    assert tuple(w.shape) == (320, 1280)
+    j = torch.arange(5).view(5, 1)
+    i = torch.arange(16).view(1, 16)
+    col = torch.where(j == 4, 64 + i, 32 * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3))  # [j, i]
+    rows = (torch.arange(4).view(4, 1, 1) * 80 + col.view(1, 5, 16)).to(w.device)                # [wc, j, i]
+    x = w[rows.reshape(-1)].view(4, 5, 16, 40, 4, 8)  # [wc, j, i = L & 15, pn, g = L >> 4, e]
+    return x.permute(3, 0, 1, 4, 2, 5).reshape(320, 1280).contiguous()  # [pn, wc, j, g, i, e]
+
+
 def frag_wanted(n: int, k: int) -> bool:
     """The shapes the activation-resident kernel takes (ca_gemm.hip ar_eligible): K = 320, N a multiple of 320, N >= 960."""
     return k == 320 and n % 320 == 0 and n >= 960

@@ -134,6 +134,37 @@ int ca_gemm(const ca_gemm_args* args, void* stream);
  * ca_gemm_args.w_frag takes; geglu = the flag of the ca_gemm calls that will use it (the weight-row interleave behind the
  * 16-byte stores differs).  Weights are packed once per model, so this runs at load time. */
 int ca_pack_w_frag(const void* w, int32_t n, int32_t k, int32_t geglu, void* dst, void* stream);
+/* ------------------------------------------------------------------------------------
+ * ca_ff_fused (ABI v9): the whole feed-forward of a transformer block in one launch,
+ *     y = GEGLU(LN(x) W1^T + b1) W2^T + b2 + residual
+ * Replaces: BasicTransformerBlock / TemporalTransformerBlock feed-forward (animatediff/models/attention.py:288,303-357:
+ *   `ff(norm3(hidden)) + hidden`; motion_module.py:203-224) at the 64x64-latent level -- LayerNorm fold, GEGLU projection and
+ *   output projection as ca_gemm computes them (same rounding of the projection output and of h to the activation type), but
+ *   the [M, 1280] intermediate stays in LDS.  Available for c = 320, inner = 1280, M >= 16384 (ca_ff_fused_supported; no
+ *   launch, no device access); everything else runs as two ca_gemm calls.
+ *   w1_frag: the LayerNorm-folded GEGLU weight [2560, 320] (rows value / gate interleaved) in the order of ca_pack_w_frag(geglu = 1);
+ *   bias1 / colsum1 [2560] fp32 as ca_gemm's bias / ln_colsum; ln_stats [M][2] (mean, rstd) or NULL = computed in the kernel
+ *   (ln_eps > 0); w2_frag: the output weight [320, 1280] in the order of ca_pack_w2_frag; bias2 [320] fp32 or NULL;
+ *   residual [M, 320] or NULL. */
+typedef struct ca_ff_args {
+  const void* x;        /* [M, c] rows at stride lda */
+  const void* w1_frag;
+  const float* bias1;
+  const float* colsum1;
+  const float* ln_stats;
+  const void* w2_frag;
+  const float* bias2;
+  const void* residual; /* [M, c] rows at stride ld_res, or NULL */
+  void* y;              /* [M, c] rows at stride ldc */
+  int64_t lda, ldc, ld_res;
+  int32_t m, c, inner;
+  float ln_eps;
+  int32_t dtype;
+} ca_ff_args;
+int ca_ff_fused(const ca_ff_args* args, void* stream);
+int ca_ff_fused_supported(const ca_ff_args* args);
+/* dst[320 * 1280] = w[320, 1280] in the fragment order ca_ff_args.w2_frag takes (16-bit elements, 16-byte aligned). */
+int ca_pack_w2_frag(const void* w, int32_t n, int32_t k, void* dst, void* stream);
 /* bytes of split-K scratch this launch can use (0: it would not split) */
 int64_t ca_gemm_workspace_bytes(const ca_gemm_args* args);
 /* partial sums per row this launch can leave in row_sums_out (0: it cannot).  N / 320 on the 128 x 320-tile kernels; ABI v8:
