@@ -97,7 +97,11 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
 
   for (int tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
     const int m0 = tile * BM;
-    const int rot = 4 * (tile % ROUNDS);  // h chunk of (round r, slot s) = (4 r + s + rot) mod 40: the blocks of a wave of tiles start on different W panels
+    // h chunk of (round r, slot s) = (4 r + s + rot) mod 40, rot = 4 (tile mod 8): the blocks of a round of tiles start on different
+    // W panels (all on panel 0: 392-420 instead of 368-405 us).  y then sums its 40 chunks in an order that depends on the tile
+    // index mod 8 only: rows 8 k tiles apart get the same bits for the same input -- the two CFG halves of identical inputs
+    // (tests/test_fullsize_gpu.py) whenever an image is a whole multiple of 8 tiles (1024 rows: every latent size of the configs).
+    const int rot = 4 * (tile & 7);
     __syncthreads();  // the previous tile's reads of the x tile and of H are over
     {
       int lane_o = lane;
