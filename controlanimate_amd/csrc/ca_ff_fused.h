@@ -95,6 +95,24 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
   asm volatile("" : "+v"(lane_k));
   const unsigned wv = (unsigned)lane_k * 16u;
 
+  // the x tile of a block's NEXT row tile is requested by the producers as soon as their last K loop of the current one is over
+  // (round 9, behind B1): it lands beside the last epilogue, the consumers' drain round and their y epilogue
+  auto x_tile_dma = [&](int tile_) __attribute__((always_inline)) {
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int m0_ = tile_ * BM;
+#pragma unroll
+    for (int q = 0; q < 20; ++q) {
+      const unsigned idx = (unsigned)((wq * 20 + q) * 64 + lane_o);
+      const unsigned r = __umulhi(idx >> 3, 0xCCCCCCCDu) >> 2;  // idx / 40
+      const unsigned cp = idx - r * 40u;
+      const unsigned c = cp ^ ((r >> 1) & 7u);
+      const unsigned off = (m0_ + (int)r) < p.m ? (unsigned)(m0_ + (int)r) * (unsigned)p.lda * 2u + c * 16u : OOB_V;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + (wq * 20 + q) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  if (producer && (int)blockIdx.x < tiles_m) x_tile_dma(blockIdx.x);
+
   for (int tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
     const int m0 = tile * BM;
     // h chunk of (round r, slot s) = (4 r + s + rot) mod 40, rot = 4 (tile mod 8): the blocks of a round of tiles start on different
@@ -102,21 +120,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
     // index mod 8 only: rows 8 k tiles apart get the same bits for the same input -- the two CFG halves of identical inputs
     // (tests/test_fullsize_gpu.py) whenever an image is a whole multiple of 8 tiles (1024 rows: every latent size of the configs).
     const int rot = 4 * (tile & 7);
-    __syncthreads();  // the previous tile's reads of the x tile and of H are over
-    {
-      int lane_o = lane;
-      asm volatile("" : "+v"(lane_o));
-#pragma unroll
-      for (int q = 0; q < 10; ++q) {
-        const unsigned idx = (unsigned)((wid * 10 + q) * 64 + lane_o);
-        const unsigned r = __umulhi(idx >> 3, 0xCCCCCCCDu) >> 2;  // idx / 40
-        const unsigned cp = idx - r * 40u;
-        const unsigned c = cp ^ ((r >> 1) & 7u);
-        const unsigned off = (m0 + (int)r) < p.m ? (unsigned)(m0 + (int)r) * (unsigned)p.lda * 2u + c * 16u : OOB_V;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + (wid * 10 + q) * 1024), 16, off, 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (producers: this tile's x pieces; consumers: the previous tile's stores)
     __syncthreads();
     {  // LayerNorm statistics: four threads per row, ten 16-byte pieces each; (mean, rstd) -> LDS
       const int r = tid >> 2, h = tid & 3;
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
         // ---- B1: the consumers' stage 2 of round r - 1 starts beside this epilogue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (r + 1 == ROUNDS && tile + (int)gridDim.x < tiles_m) x_tile_dma(tile + gridDim.x);  // (every producer's reads of the x tile are over)
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int l15 = lane_e & 15, g = lane_e >> 4;

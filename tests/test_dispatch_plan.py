@@ -194,3 +194,23 @@ def test_activation_resident_kernel_only_takes_what_it_implements(capi):
     # ca_pack_w_frag argument checks
     for args in ((None, 960, 320, 0, FAKE), (FAKE, 960, 640, 0, FAKE), (FAKE, 100, 320, 0, FAKE), (FAKE, 960, 320, 0, 0x10008)):
         assert lib.ca_pack_w_frag(args[0], args[1], args[2], args[3], args[4], None) < 0 and b"ca_pack_w_frag" in lib.ca_last_error()
+
+
+def test_fused_feed_forward_only_takes_what_it_implements(capi):
+    """ABI v9 ca_ff_fused_supported: C = 320, inner 1280, M >= 16384, 16-byte aligned operands, in-kernel statistics need ln_eps."""
+    lib = capi.lib()
+
+    def ok(**over):
+        kw = dict(x=FAKE, w1_frag=FAKE, bias1=FAKE, colsum1=FAKE, w2_frag=FAKE, bias2=FAKE, residual=FAKE, y=FAKE, lda=320, ldc=320, ld_res=320,
+                  m=131072, c=320, inner=1280, ln_eps=1e-5, dtype=capi.CA_F16)
+        kw.update(over)
+        return lib.ca_ff_fused_supported(C.byref(capi.FfArgs(**kw)))
+
+    assert ok() == 1 and ok(residual=None, ld_res=0) == 1 and ok(bias2=None) == 1 and ok(ln_stats=FAKE, ln_eps=0.0) == 1 and ok(dtype=capi.CA_BF16) == 1
+    assert ok(m=8192) == 0 and ok(c=640) == 0 and ok(inner=2560) == 0 and ok(w1_frag=None) == 0 and ok(w2_frag=None) == 0
+    assert ok(lda=324) == 0 and ok(x=FAKE + 8) == 0 and ok(ln_eps=0.0) == 0 and ok(dtype=7) == 0
+    assert ok(m=1 << 23, lda=320) == 0  # 32-bit byte offsets
+    bad = capi.FfArgs(x=FAKE, m=100)
+    assert lib.ca_ff_fused(C.byref(bad), None) < 0 and b"ca_ff_fused" in lib.ca_last_error()
+    for args in ((None, 320, 1280, FAKE), (FAKE, 640, 1280, FAKE), (FAKE, 320, 1280, 0x10008)):
+        assert lib.ca_pack_w2_frag(args[0], args[1], args[2], args[3], None) < 0

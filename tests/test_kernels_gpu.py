@@ -606,6 +606,42 @@ def test_gemm_activation_resident_k320(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_ff_fused_c320(dtype):
+    """ca_ff_fused (ABI v9, csrc/ca_ff_fused.h): the feed-forward of the 64x64-latent level -- folded LayerNorm with in-kernel
+    statistics, GEGLU projection, output projection, residual -- in one launch, against fp32 torch (the reference's arithmetic:
+    animatediff/models/attention.py:288,303-357) and against the two ca_gemm calls it replaces; ragged M (a last tile of 72 rows),
+    strided x, no residual; bit-for-bit repeatable; ca_pack_w2_frag == layers.frag_order2; outside its shapes the entry says no."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ff_check
+    from controlanimate_amd import _capi
+    from controlanimate_amd.layers import frag_order2
+    k = _k()
+    tol = 2e-3 if dtype == torch.float16 else 1.2e-2
+    for (m, lda, res) in ((16384, 320, True), (16384 + 72, 320, True), (20480, 640, False)):
+        d = ff_check.make(m, dtype, lda=lda)
+        k._plan_sink = labels = []
+        try:
+            outs = [ff_check.fused(d, res) for _ in range(2)]
+        finally:
+            k._plan_sink = None
+        assert outs[0] is not None and labels == ["ff_fused128", "ff_fused128"]
+        ref, two = ff_check.reference(d, res), ff_check.two_gemms(d, res)
+        rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
+        assert torch.isfinite(outs[0].float()).all() and rel < tol, (m, rel)
+        assert torch.equal(outs[0], outs[1])
+        assert ((outs[0].float() - two.float()).norm() / ref.norm()).item() < tol / 4
+    w2 = rnd(320, 1280, dtype=dtype, seed=13).to(DEV)
+    dst = torch.empty_like(w2)
+    _capi.check(k.lib().ca_pack_w2_frag(w2.data_ptr(), 320, 1280, dst.data_ptr(), None), "ca_pack_w2_frag")
+    torch.cuda.synchronize()
+    assert torch.equal(dst, frag_order2(w2))
+    # shapes the kernel does not take: the caller gets None and runs the two GEMMs
+    d = ff_check.make(8192, dtype)
+    assert ff_check.fused(d) is None
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,c", [(8192, 1280), (32768 - 24, 640)])
 def test_layernorm_statistics_handed_from_producer_to_consumer(m, c, dtype):
     """ABI v6 row_sums_out / ln_parts: the GEMM that writes a tensor leaves (sum, sum of squares) of every stored row per
