@@ -16,8 +16,13 @@
 // overlapped with at two free-running blocks per CU): { producers: K loop | consumers: wait } B1 { producers: epilogue -> H |
 // consumers: stage 2 of the previous round } B2.  Producers never store to memory, so nothing in their W stream waits behind a
 // store (the in-order VMEM counter, ca_gemm_ar.h); consumers store once per tile.
-// LayerNorm statistics: four threads per row over the landed tile, kept in 1 KB of LDS.  The residual of the reference's
-// feed-forward is the block's own input (attention.py:350-357 `ff(norm3(x)) + x`): read from global like any residual.
+// LayerNorm: four threads per row normalise the landed tile IN PLACE ((x - mean) * rstd rounded to the activation type, gamma / beta
+// folded into W1 / bias1), so the GEGLU epilogue is acc + bias.  The residual of the reference's feed-forward is the block's own
+// input (attention.py:350-357 `ff(norm3(x)) + x`): read from global like any residual (the LDS copy is normalised).
+// s_memtime stamps of a round (tools/ff_stamps.py, experiments build): producer K loop 6.0-6.3 k cycles (19 per MFMA), epilogue
+// 9.4 k beside the consumer's 160 MFMAs (4.9 k): on this chip a SIMD's VALU and matrix work do not overlap -- the consumer's MFMAs
+// take 31 cycles each beside the epilogue, 17 alone -- so a round costs the SUM of its MFMA and VALU work whatever the schedule;
+// what is left to gain is instruction count (the degree-9 GELU polynomial is 60 % of the epilogue).
 //
 // Fragment-ordered W2 (ca_pack_w2_frag): 16-byte piece L of MFMA tile j (5 per 80-column wave range, the 16-byte-store interleave of
 // ca_gemm_ps.h) of consumer wave wc of h chunk pn (40 chunks of 32):  W2[wc * 80 + col5(j, L & 15)][pn * 32 + (L >> 4) * 8 : +8]
@@ -57,8 +62,24 @@ struct FfParams {
   unsigned x_bytes, y_bytes, res_bytes;
 };
 
+#ifdef CA_EXPERIMENTS
+// (timing experiments: shader-clock stamps of block 0, wave 0 (producer) / wave 4 (consumer), first tile: tools/ff_stamps.py)
+__device__ unsigned long long ca_ff_stamps[2][256];
+#define CA_FF_STAMP(TAG)                                                                                         \
+  if (blockIdx.x == 0 && tile == (int)blockIdx.x && (wid == 0 || wid == 4) && lane == 0 && stamp_i < 120) {     \
+    ca_ff_stamps[wid >> 2][2 * stamp_i] = __builtin_readcyclecounter();                                          \
+    ca_ff_stamps[wid >> 2][2 * stamp_i + 1] = (TAG);                                                              \
+    ++stamp_i;                                                                                                   \
+  }
+#else
+#define CA_FF_STAMP(TAG)
+#endif
+
 template <int DT>
 __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
+#ifdef CA_EXPERIMENTS
+  int stamp_i = 0;
+#endif
   constexpr int K = 320, KQ = 10, TM = 8, TN = 4, BM = 128, PANELS = 40, ROUNDS = 10;
   constexpr int ROWB = K * 2;
   constexpr int H_BYTES = BM * 256;
@@ -66,8 +87,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
   // LDS-DMA destination -- only the x tile is one
   __shared__ __attribute__((aligned(16))) unsigned char smem[BM * ROWB];
   __shared__ __attribute__((aligned(16))) unsigned char smem_h[2 * H_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char smem_st[BM * 8];
-  static_assert(BM * ROWB + 2 * H_BYTES + BM * 8 <= 160 * 1024, "LDS");
+  static_assert(BM * ROWB + 2 * H_BYTES <= 160 * 1024, "LDS");
   constexpr unsigned OOB_V = 0x80000000u;
 
   const int tid = threadIdx.x;
@@ -81,7 +101,6 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
   const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1f, 0, 2560u * 640u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2f, 0, 320u * 2560u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias1, 0, 2560u * 4u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_c1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.cs1, 0, 2560u * 4u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias2 ? (const void*)p.bias2 : (const void*)p.w2f), 0, p.bias2 ? 320u * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.y), 0, p.res ? p.res_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
@@ -122,20 +141,25 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
     const int rot = 4 * (tile & 7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (producers: this tile's x pieces; consumers: the previous tile's stores)
     __syncthreads();
-    {  // LayerNorm statistics: four threads per row, ten 16-byte pieces each; (mean, rstd) -> LDS
+    {  // LayerNorm: four threads per row, ten 16-byte pieces each.  The tile is normalised IN PLACE -- x' = (x - mean) * rstd, rounded
+       // to the activation type as the reference's LayerNorm output is (gamma and beta live in W1 and bias1: layers.LnFold) -- so that
+       // the GEGLU epilogue is acc + bias: folding (mean, rstd) into the epilogue instead (ca_gemm) costs two more VALU operations and
+       // two more operands per value there, and on this chip a SIMD's VALU and matrix work do not overlap (tools/ff_stamps.py).
       const int r = tid >> 2, h = tid & 3;
+      unsigned char* src = smem + r * ROWB + h * 160;
+      u32x4 v[10];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) v[q] = ld16(src + q * 16);
       float2 st;
       if (p.ln_stats) {
         st = (m0 + r < p.m) ? *reinterpret_cast<const float2*>(p.ln_stats + (int64_t)(m0 + r) * 2) : make_float2(0.f, 0.f);
       } else {
-        const unsigned char* src = smem + r * ROWB + h * 160;
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int q = 0; q < 10; ++q) {
-          const u32x4 v = ld16(src + ((q + r) % 10) * 16);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float a0 = Elem<DT>::to_f((u16)(v[e] & 0xffffu)), a1 = Elem<DT>::to_f((u16)(v[e] >> 16));
+            const float a0 = Elem<DT>::to_f((u16)(v[q][e] & 0xffffu)), a1 = Elem<DT>::to_f((u16)(v[q][e] >> 16));
             s += a0 + a1;
             ss = fmaf(a0, a0, fmaf(a1, a1, ss));
           }
@@ -147,10 +171,20 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
         const float mean = s * (1.f / K);
         st = make_float2(mean, rsqrtf(fmaxf(ss * (1.f / K) - mean * mean, 0.f) + p.ln_eps));
       }
-      if (h == 0) *reinterpret_cast<float2*>(smem_st + r * 8) = st;
+      const float nb = -st.x * st.y;
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = Elem<DT>::to_f((u16)(v[q][e] & 0xffffu)), a1 = Elem<DT>::to_f((u16)(v[q][e] >> 16));
+          v[q][e] = pack2<DT>(fmaf(a0, st.y, nb), fmaf(a1, st.y, nb));
+        }
+        st16(src + q * 16, v[q]);
+      }
     }
     __syncthreads();
 
+    CA_FF_STAMP(0)
     if (producer) {
       // ================================================================ producers: GEGLU items -> H
       u32x4 fa[TM], fb[2][TN];
@@ -196,8 +230,10 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
           }
         }
         // ---- B1: the consumers' stage 2 of round r - 1 starts beside this epilogue
+        CA_FF_STAMP(1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        CA_FF_STAMP(2)
         if (r + 1 == ROUNDS && tile + (int)gridDim.x < tiles_m) x_tile_dma(tile + gridDim.x);  // (every producer's reads of the x tile are over)
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
@@ -209,37 +245,31 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w1, wv, wb1 + (unsigned)(c * TN + j) * 1024u, 0));
         }
-        f32x4 bi[TN], cs[TN];
+        f32x4 bi[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const unsigned c4 = (unsigned)(pn * 64 + 16 * g + 4 * j) * 4u;
-          bi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b1, c4, 0, 0));
-          cs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c1, c4, 0, 0));
-        }
+        for (int j = 0; j < TN; ++j) bi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b1, (unsigned)(pn * 64 + 16 * g + 4 * j) * 4u, 0, 0));
         unsigned char* hb = smem_h + (r & 1) * H_BYTES;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int row = i * 16 + l15;
-          const float2 st = *reinterpret_cast<const float2*>(smem_st + row * 8);
           unsigned w[TN];
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float x = st.y * (acc[i][j][q] - st.x * cs[j][q]);
-              v[q] = Elem<DT>::to_f(Elem<DT>::from_f(x + bi[j][q]));  // (the Linear's output is rounded first)
-            }
-            const f32x2 gg = gelu_erf_f2((f32x2){v[1], v[3]});
-            w[j] = pack2<DT>(v[0] * gg[0], v[2] * gg[1]);
+            // (value, gate) pairs: the gates go through the activation type (the Linear's output as the GELU sees it), the values
+            // meet them in fp32 -- one rounding of the product instead of two
+            const float g0 = Elem<DT>::to_f(Elem<DT>::from_f(acc[i][j][1] + bi[j][1])), g1 = Elem<DT>::to_f(Elem<DT>::from_f(acc[i][j][3] + bi[j][3]));
+            const f32x2 gg = gelu_erf_f2((f32x2){g0, g1});
+            w[j] = pack2<DT>((acc[i][j][0] + bi[j][0]) * gg[0], (acc[i][j][2] + bi[j][2]) * gg[1]);
           }
           // h[row][slot wq: 32 columns, this lane's 8 at 8 g]: logical 16-byte chunk 4 wq + g of the 256-byte row, at chunk ^ (row & 15)
           *reinterpret_cast<u32x4*>(hb + row * 256 + (((wq * 4 + g) ^ l15) << 4)) = (u32x4){w[0], w[1], w[2], w[3]};
           __builtin_amdgcn_sched_barrier(0);
         }
         // ---- B2: H[r & 1] is complete; the consumers' reads of H[(r - 1) & 1] are over
+        CA_FF_STAMP(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        CA_FF_STAMP(4)
       }
       // the drain round (consumers: stage 2 of round 9) and the consumers' epilogue: two more barriers
       __builtin_amdgcn_s_barrier();
@@ -261,7 +291,9 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
       };
       for (int r = 0; r <= ROUNDS; ++r) {
         if (r >= 1) w2_load(r - 1, 0, 0);  // (lands while the producers finish their K loop)
+        CA_FF_STAMP(1)
         __builtin_amdgcn_s_barrier();      // B1
+        CA_FF_STAMP(2)
         if (r >= 1) {
           const unsigned char* hb = smem_h + ((r - 1) & 1) * H_BYTES;
 #pragma unroll
@@ -280,8 +312,10 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+        CA_FF_STAMP(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (r < ROUNDS) __builtin_amdgcn_s_barrier();  // B2
+        CA_FF_STAMP(4)
       }
       // ---- y epilogue: + bias + residual, 16-byte stores (pairs of MFMA tiles interleaved, ca_gemm_ps.h)
       int lane_e = lane;

@@ -98,3 +98,9 @@ extern "C" int ca_ff_fused(const ca_ff_args* a, void* stream) {
   CA_CHECK_LAUNCH("ca_ff_fused");
   return CA_OK;
 }
+
+#ifdef CA_EXPERIMENTS
+extern "C" int ca_debug_ff_stamps(unsigned long long* out) {  // 2 x 256 words, host pointer
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_ff_stamps), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -630,7 +630,9 @@ def test_ff_fused_c320(dtype):
         rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
         assert torch.isfinite(outs[0].float()).all() and rel < tol, (m, rel)
         assert torch.equal(outs[0], outs[1])
-        assert ((outs[0].float() - two.float()).norm() / ref.norm()).item() < tol / 4
+        # (the fused kernel normalises its x tile in place, i.e. rounds LN(x) to the activation type as the reference does; the
+        #  two-GEMM path folds (mean, rstd) into the epilogue in fp32: one operand rounding apart)
+        assert ((outs[0].float() - two.float()).norm() / ref.norm()).item() < tol / 2
     w2 = rnd(320, 1280, dtype=dtype, seed=13).to(DEV)
     dst = torch.empty_like(w2)
     _capi.check(k.lib().ca_pack_w2_frag(w2.data_ptr(), 320, 1280, dst.data_ptr(), None), "ca_pack_w2_frag")

@@ -67,7 +67,7 @@ def check():
             diff = ((outs[0].float() - two.float()).norm() / ref.norm()).item()
             same = all(torch.equal(outs[0], o) for o in outs[1:])
             tol = 2e-3 if dt == torch.float16 else 1.2e-2
-            ok = rel < tol and same and bool(torch.isfinite(outs[0].float()).all()) and diff < tol / 2
+            ok = rel < tol and same and bool(torch.isfinite(outs[0].float()).all()) and diff < tol / 2  # (one operand rounding apart: LN(x) rounded to the activation type in the fused kernel)
             bad += not ok
             print(f"{str(dt)[6:]:9s} m={m:6d} lda={lda} residual={res}: fused rel {rel:.2e}, two GEMMs rel {rel2:.2e}, fused vs two {diff:.2e}, deterministic={same}{'' if ok else '   <<<<<< FAIL'}", flush=True)
     return bad
