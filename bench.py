@@ -167,6 +167,8 @@ def rocprof_kernel_name(family: str, dtype: str) -> str:
         return f"k_gemm_wres<{dt}>"
     if tile == "ar128x64":  # (every epilogue variant: k_gemm_ar<dt, EPI>)
         return f"k_gemm_ar<{dt}, "
+    if tile == "fused128":  # family "ff_fused128": both GEMMs of a feed-forward in one launch
+        return f"k_ff_fused<{dt}>"
     if tile.startswith("pp128x320"):
         return f"k_gemm_pp2<{dt}, {mode}"
     if tile == "ps128x320":
@@ -186,6 +188,8 @@ def kernel_display_name(family: str) -> str:
         return f"k_gemm_wres<{family}>"
     if tile == "ar128x64":
         return f"k_gemm_ar<{family}>"
+    if tile == "fused128":
+        return f"k_ff_fused<{family}>"
     if tile.startswith("pp128x320"):
         return f"k_gemm_pp2<{family}>"
     if tile == "ps128x320":
@@ -271,7 +275,24 @@ class KernelTimer:
                                   (mrows, n, 9 * w.shape[3])))
             return out
 
-        K.gemm, K.conv3x3 = gemm, conv3x3
+        ff0 = K.ff_fused
+
+        def ff_fused(x, w1_frag, bias1, colsum1, w2_frag, bias2, ln_eps, **kw):
+            if not timer.enabled:
+                return ff0(x, w1_frag, bias1, colsum1, w2_frag, bias2, ln_eps, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = ff0(x, w1_frag, bias1, colsum1, w2_frag, bias2, ln_eps, **kw)
+            e.record()
+            if out is not None:  # (None: the library does not take the arguments, the caller runs the two GEMMs -- timed there)
+                m, c = x.shape
+                inner = w2_frag.shape[1]
+                # x, y (+ residual) once, both weight matrices once; the [m, inner] intermediate never leaves the CU
+                timer.bytes[id(s)] = 2.0 * (m * c * (3 if kw.get("residual") is not None else 2) + 3 * inner * c)
+                timer.records.append(("ff_fused128", 2.0 * m * c * 2 * inner + 2.0 * m * inner * c, s, e, (m, 3 * inner, c)))
+            return out
+
+        K.gemm, K.conv3x3, K.ff_fused = gemm, conv3x3, ff_fused
 
         def wrap_other(name, shape_of):
             fn0 = getattr(K, name)
