@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CA_HIP_LIB") or os.path.join(_HERE, "csrc", "libcontr
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class CAHipUnavailable(RuntimeError):
@@ -48,6 +48,18 @@ class FfArgs(C.Structure):
         ("lda", C.c_int64), ("ldc", C.c_int64), ("ld_res", C.c_int64),
         ("m", C.c_int32), ("c", C.c_int32), ("inner", C.c_int32), ("ln_eps", C.c_float), ("dtype", C.c_int32),
     ]
+
+
+class TattnArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w_frag", C.c_void_p), ("gamma", C.c_void_p), ("bias_pe", C.c_void_p), ("o", C.c_void_p),
+        ("lda", C.c_int64), ("ldo", C.c_int64), ("ld_bias_pe", C.c_int64),
+        ("batch", C.c_int32), ("frames", C.c_int32), ("tokens", C.c_int32), ("heads", C.c_int32), ("c", C.c_int32),
+        ("ln_eps", C.c_float), ("scale", C.c_float), ("dtype", C.c_int32),
+    ]
+
+
+TATTN_W_FRAG_ELEMS = 368640  # CA_TATTN_W_FRAG_ELEMS
 
 
 class ConvArgs(C.Structure):
@@ -109,6 +121,9 @@ SYMBOLS = {
     "ca_pack_w2_frag": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ca_ff_fused": (C.c_int, [C.POINTER(FfArgs), C.c_void_p]),
     "ca_ff_fused_supported": (C.c_int, [C.POINTER(FfArgs)]),
+    "ca_tattn_fused": (C.c_int, [C.POINTER(TattnArgs), C.c_void_p]),
+    "ca_tattn_fused_supported": (C.c_int, [C.POINTER(TattnArgs)]),
+    "ca_pack_w_tattn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ca_gemm_ln_inline_supported": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_gemm_wants_finished_stats": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_ln_finish_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

@@ -45,6 +45,13 @@ class AttnProcessor2_0(nn.Module):
         B, N, C = hidden_states.shape
         x = hidden_states.reshape(B * N, C)
         res = None if residual is None else residual.reshape(B * N, C)
+        if ln is not None and encoder_hidden_states is None and temporal is not None and getattr(attn, "tfrag", None) is not None:
+            # LayerNorm + positional encoding + q|k|v + attention over the frames in one launch where the library takes the shape
+            b, f, n = temporal
+            o = K.tattn_fused(x, attn.tfrag.t, attn.tgamma.t, attn.tbias_pe.t, b, f, n, attn.heads, attn.tln_eps, attn.scale)
+            if o is not None:
+                out = attn.to_out[0].run(o, residual=res, row_sums=row_sums)
+                return K.carry_row_sums(out.reshape(B, N, C), out)
         if ln is not None:
             st, fold = ln
             if encoder_hidden_states is None and temporal is not None and fold.pe is not None:

@@ -80,6 +80,10 @@ struct Elem<CA_F16> {
   }
 };
 
+// Two fp32 values -> one register of two 16-bit elements, round to nearest even.  (Round 4: written as a vector conversion hipcc
+// emits ONE v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 instead of the 3-4 instructions below -- measured on the whole step: no gain
+// (61.04 / 60.74 vs 60.89 / 60.36 ms), and the bf16 d = 40 attention kernel then returns wrong values (rel 0.1: the packed
+// conversion reads MFMA results the hazard recogniser does not protect).  Kept scalar.)
 template <int DT>
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   return (unsigned)Elem<DT>::from_f(lo) | ((unsigned)Elem<DT>::from_f(hi) << 16);
@@ -177,6 +181,15 @@ __device__ __forceinline__ float rowgroup_max(float m) {
   u = __float_as_uint(vmax2(__uint_as_float(a[0]), __uint_as_float(a[1])));
   u32x2 b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   return vmax2(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// sum over the four 16-lane rows, result in every lane (same two swaps)
+__device__ __forceinline__ float rowgroup_sum(float m) {
+  unsigned u = __float_as_uint(m);
+  u32x2 a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+  u32x2 b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }

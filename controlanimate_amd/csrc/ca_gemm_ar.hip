@@ -5,6 +5,7 @@ namespace {
 using namespace ca_gemm_detail;
 #include "ca_gemm_ar.h"
 #include "ca_ff_fused.h"
+#include "ca_tattn_fused.h"
 
 int ar_cu_count() {
   static int n = 0;
@@ -96,6 +97,58 @@ extern "C" int ca_ff_fused(const ca_ff_args* a, void* stream) {
   if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_ff_fused<CA_BF16>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
   else hipLaunchKernelGGL((k_ff_fused<CA_F16>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
   CA_CHECK_LAUNCH("ca_ff_fused");
+  return CA_OK;
+}
+
+extern "C" int ca_pack_w_tattn(const void* w, int32_t n, int32_t k, void* dst, void* stream) {
+  CA_REQUIRE(w && dst, "ca_pack_w_tattn: null operand");
+  CA_REQUIRE(n == 960 && k == 320, "ca_pack_w_tattn: n=%d k=%d (Wq | Wk | Wv rows: 960 x 320)", n, k);
+  CA_REQUIRE((((uintptr_t)w | (uintptr_t)dst) & 15) == 0, "ca_pack_w_tattn: operands must be 16-byte aligned");
+  static_assert(CA_TATTN_WF_ELEMS == CA_TATTN_W_FRAG_ELEMS, "header constant");
+  hipLaunchKernelGGL(k_pack_w_tattn, dim3((CA_TATTN_WF_ELEMS / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u16*)w, (u16*)dst);
+  CA_CHECK_LAUNCH("ca_pack_w_tattn");
+  return CA_OK;
+}
+
+extern "C" int ca_tattn_fused_supported(const ca_tattn_args* a) {
+  if (!a || !a->x || !a->w_frag || !a->gamma || !a->bias_pe || !a->o) return 0;
+  if (a->c != 320 || a->heads != 8 || a->frames != 16 || a->batch < 1 || a->tokens < 8 || a->tokens % 8) return 0;
+  if (a->dtype != CA_BF16 && a->dtype != CA_F16) return 0;
+  const int64_t rows = (int64_t)a->batch * a->frames * a->tokens;
+  if (rows < 16384) return 0;
+  if (a->lda % 8 || a->ldo % 8 || a->lda < 320 || a->ldo < 320 || a->ld_bias_pe % 4 || a->ld_bias_pe < 320) return 0;
+  if ((((uintptr_t)a->x | (uintptr_t)a->o | (uintptr_t)a->w_frag | (uintptr_t)a->gamma | (uintptr_t)a->bias_pe) & 15) != 0) return 0;
+  const int64_t lim = 0x7FFFFF00ll;
+  if (((rows - 1) * a->lda + 320) * 2 >= lim || ((rows - 1) * a->ldo + 320) * 2 >= lim) return 0;
+  if (!(a->ln_eps > 0.f) || !(a->scale > 0.f)) return 0;
+  return 1;
+}
+
+extern "C" int ca_tattn_fused(const ca_tattn_args* a, void* stream) {
+  CA_REQUIRE(a != nullptr, "ca_tattn_fused: null args");
+  CA_REQUIRE(ca_tattn_fused_supported(a), "ca_tattn_fused: arguments outside what the fused temporal attention takes (C = 320, 8 heads, 16 frames, tokens %% 8 == 0, "
+                                           ">= 16384 rows, fragment-ordered weights, 16-byte aligned operands, 32-bit byte offsets): ask ca_tattn_fused_supported() first");
+  const int64_t rows = (int64_t)a->batch * a->frames * a->tokens;
+  TattnParams p{};
+  p.x = (const u16*)a->x;
+  p.wf = (const u16*)a->w_frag;
+  p.gamma = a->gamma;
+  p.bp = a->bias_pe;
+  p.o = (u16*)a->o;
+  p.lda = (int)a->lda, p.ldo = (int)a->ldo, p.ld_bp = (int)a->ld_bias_pe;
+  p.hw = a->tokens;
+  p.ln_eps = a->ln_eps;
+  p.scale_log2 = a->scale * 1.4426950408889634f;
+  p.x_bytes = (unsigned)(((rows - 1) * a->lda + 320) * 2);
+  p.o_bytes = (unsigned)(((rows - 1) * a->ldo + 320) * 2);
+  const int tiles = (int)((int64_t)a->batch * a->tokens / 8);
+  static const int dbg = CA_KNOB("CA_TATTN_DBG", 0);
+  p.dbg = dbg;
+  const int slots = (dbg & 16) ? ar_cu_count() : 2 * ar_cu_count();  // (16: one block per CU -- stamps of a wave that has its SIMD to itself)
+  const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+  if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_tattn_fused<CA_BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles);
+  else hipLaunchKernelGGL((k_tattn_fused<CA_F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles);
+  CA_CHECK_LAUNCH("ca_tattn_fused");
   return CA_OK;
 }
 

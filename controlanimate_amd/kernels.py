@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import (AttnArgs, ConvArgs, FfArgs, GemmArgs, GroupNormArgs, LayerNormArgs, CA_ACT_NONE,
+from ._capi import (AttnArgs, ConvArgs, FfArgs, TattnArgs, GemmArgs, GroupNormArgs, LayerNormArgs, CA_ACT_NONE,
                     CA_ACT_SILU, CA_BF16, CA_F16, check, lib)
 
 ACT_NONE, ACT_SILU = CA_ACT_NONE, CA_ACT_SILU
@@ -174,6 +174,32 @@ def ff_fused(x: torch.Tensor, w1_frag: torch.Tensor, bias1: torch.Tensor, colsum
         _plan_sink.append("ff_fused128")
     check(lib().ca_ff_fused(C.byref(args), _stream()), "ca_ff_fused")
     return y
+
+
+_TATTN_FUSED_ON = os.environ.get("CA_TATTN_FUSED", "1") != "0"  # (0: temporal attention always as q|k|v GEMM + attention -- A/B runs)
+
+
+def tattn_fused(x: torch.Tensor, w_frag: torch.Tensor, gamma: torch.Tensor, bias_pe: torch.Tensor, b: int, frames: int, tokens: int,
+                heads: int, ln_eps: float, scale: float) -> Optional[torch.Tensor]:
+    """o = softmax(q k^T scale) v over the frame axis with q|k|v = (LayerNorm(x) + pe[frame]) Wqkv^T in one launch (ca_tattn_fused,
+    ABI v10: the motion modules of the 64x64-latent level) -- or None where the library does not take the arguments (the caller
+    then runs the folded q|k|v GEMM and attention_temporal).  x rows in (b f n) order; bias_pe [>= frames, C] fp32."""
+    if not _TATTN_FUSED_ON:
+        return None
+    _req_cuda(x, w_frag, gamma, bias_pe)
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[0] != b * frames * tokens or bias_pe.shape[0] < frames or bias_pe.stride(1) != 1:
+        return None
+    c = x.shape[1]
+    o = torch.empty((x.shape[0], c), device=x.device, dtype=x.dtype)
+    args = TattnArgs(x=_p(x), w_frag=_p(w_frag), gamma=_p(gamma), bias_pe=_p(bias_pe), o=_p(o), lda=x.stride(0), ldo=o.stride(0),
+                     ld_bias_pe=bias_pe.stride(0), batch=b, frames=frames, tokens=tokens, heads=heads, c=c, ln_eps=float(ln_eps),
+                     scale=float(scale), dtype=dt_code(x.dtype))
+    if not lib().ca_tattn_fused_supported(C.byref(args)):
+        return None
+    if _plan_sink is not None:
+        _plan_sink.append("tattn_fused128")
+    check(lib().ca_tattn_fused(C.byref(args), _stream()), "ca_tattn_fused")
+    return o
 
 
 _ROW_SUMS_ON = os.environ.get("CA_LN_ROWSUMS", "1") != "0"  # (0: always the separate statistics pass -- A/B runs)

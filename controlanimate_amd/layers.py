@@ -110,6 +110,17 @@ def frag_order2(w: torch.Tensor) -> torch.Tensor:
     return x.permute(3, 0, 1, 4, 2, 5).reshape(320, 1280).contiguous()  # [pn, wc, j, g, i, e]
 
 
+def frag_order_tattn(wqkv: torch.Tensor) -> torch.Tensor:
+    """[960, 320] (rows Wq | Wk | Wv of 8 heads x 40) -> the flat order ca_tattn_args.w_frag takes (= ca_pack_w_tattn,
+    csrc/ca_tattn_fused.h): 16-byte piece L of column tile j of 32-deep chunk kq of pass ps (q, k, v) of head wv + 4 hi holds
+    W_ps[head * 40 + 16 j + (L & 15)][kq * 32 + (L >> 4) * 8 : + 8], zeros where 16 j + (L & 15) >= 40."""
+    assert tuple(wqkv.shape) == (960, 320)
+    wpad = wqkv.new_zeros(3, 8, 48, 320)
+    wpad[:, :, :40] = wqkv.view(3, 8, 40, 320)
+    x = wpad.view(3, 2, 4, 3, 16, 10, 4, 8)  # [ps, hi, wv, j, i = L & 15, kq, g = L >> 4, e]
+    return x.permute(2, 1, 0, 5, 3, 6, 4, 7).reshape(-1).contiguous()  # [wv, hi, ps, kq, j, g, i, e]
+
+
 def frag_wanted(n: int, k: int) -> bool:
     """The shapes the activation-resident kernel takes (ca_gemm.hip ar_eligible): K = 320, N a multiple of 320, N >= 960."""
     return k == 320 and n % 320 == 0 and n >= 960

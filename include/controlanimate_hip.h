@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 9
+#define CA_ABI_VERSION 10
 
 /* element types */
 #define CA_BF16 0
@@ -165,6 +165,30 @@ int ca_ff_fused(const ca_ff_args* args, void* stream);
 int ca_ff_fused_supported(const ca_ff_args* args);
 /* dst[320 * 1280] = w[320, 1280] in the fragment order ca_ff_args.w2_frag takes (16-bit elements, 16-byte aligned). */
 int ca_pack_w2_frag(const void* w, int32_t n, int32_t k, void* dst, void* stream);
+/* ABI v10: the motion module's temporal self-attention of the 64x64-latent level up to (not including) its output projection,
+ *   o = softmax(q k^T * scale) v per (pixel, head) over the frames,  q | k | v = (LayerNorm(x) + pe[frame]) Wqkv^T,
+ * in one launch (animatediff/models/motion_module.py:251-331: norm, pos_encoder, to_q / to_k / to_v, attention with the frames
+ * as the sequence).  Rows of x and o are in (batch, frame, token) order.  Takes c = 320, 8 heads, 16 frames, tokens % 8 == 0,
+ * >= 16384 rows (ca_tattn_fused_supported: no launch, no device access); everything else runs as ca_gemm + ca_attention.
+ *   w_frag: CA_TATTN_W_FRAG_ELEMS 16-bit elements in the order of ca_pack_w_tattn (the UNFOLDED Wq | Wk | Wv);
+ *   gamma [c] fp32: the LayerNorm weight; bias_pe [frames][ld_bias_pe] fp32: LayerNorm bias + positional encoding of the frame. */
+#define CA_TATTN_W_FRAG_ELEMS 368640
+typedef struct ca_tattn_args {
+  const void* x;        /* [batch * frames * tokens, c] rows at stride lda */
+  const void* w_frag;
+  const float* gamma;
+  const float* bias_pe;
+  void* o;              /* [batch * frames * tokens, c] rows at stride ldo */
+  int64_t lda, ldo, ld_bias_pe;
+  int32_t batch, frames, tokens, heads, c;
+  float ln_eps, scale;  /* scale = head_dim ** -0.5 */
+  int32_t dtype;
+} ca_tattn_args;
+int ca_tattn_fused(const ca_tattn_args* args, void* stream);
+int ca_tattn_fused_supported(const ca_tattn_args* args);
+/* dst[CA_TATTN_W_FRAG_ELEMS] = w[960, 320] (rows Wq, Wk, Wv) in the fragment order ca_tattn_args.w_frag takes (head dim 40
+ * padded to 48 with zero rows; 16-bit elements, 16-byte aligned). */
+int ca_pack_w_tattn(const void* w, int32_t n, int32_t k, void* dst, void* stream);
 /* bytes of split-K scratch this launch can use (0: it would not split) */
 int64_t ca_gemm_workspace_bytes(const ca_gemm_args* args);
 /* partial sums per row this launch can leave in row_sums_out (0: it cannot).  N / 320 on the 128 x 320-tile kernels; ABI v8:

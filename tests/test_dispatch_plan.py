@@ -214,3 +214,25 @@ def test_fused_feed_forward_only_takes_what_it_implements(capi):
     assert lib.ca_ff_fused(C.byref(bad), None) < 0 and b"ca_ff_fused" in lib.ca_last_error()
     for args in ((None, 320, 1280, FAKE), (FAKE, 640, 1280, FAKE), (FAKE, 320, 1280, 0x10008)):
         assert lib.ca_pack_w2_frag(args[0], args[1], args[2], args[3], None) < 0
+
+
+def test_fused_temporal_attention_only_takes_what_it_implements(capi):
+    """ABI v10 ca_tattn_fused_supported: C = 320, 8 heads, 16 frames, tokens % 8 == 0, >= 16384 rows, aligned operands."""
+    lib = capi.lib()
+
+    def ok(**over):
+        kw = dict(x=FAKE, w_frag=FAKE, gamma=FAKE, bias_pe=FAKE, o=FAKE, lda=320, ldo=320, ld_bias_pe=320, batch=2, frames=16, tokens=4096,
+                  heads=8, c=320, ln_eps=1e-5, scale=40 ** -0.5, dtype=capi.CA_F16)
+        kw.update(over)
+        return lib.ca_tattn_fused_supported(C.byref(capi.TattnArgs(**kw)))
+
+    assert ok() == 1 and ok(dtype=capi.CA_BF16) == 1 and ok(batch=1, tokens=1024) == 1 and ok(lda=640, tokens=6144) == 1
+    assert ok(frames=8) == 0 and ok(frames=32) == 0 and ok(heads=4) == 0 and ok(c=640) == 0 and ok(tokens=4100) == 0
+    assert ok(batch=1, tokens=64) == 0  # 1024 rows: not worth a launch of 512 blocks
+    assert ok(w_frag=None) == 0 and ok(gamma=None) == 0 and ok(bias_pe=None) == 0 and ok(x=FAKE + 8) == 0
+    assert ok(lda=324) == 0 and ok(ld_bias_pe=318) == 0 and ok(ln_eps=0.0) == 0 and ok(scale=0.0) == 0 and ok(dtype=7) == 0
+    assert ok(batch=64, tokens=1 << 16) == 0  # 32-bit byte offsets
+    bad = capi.TattnArgs(x=FAKE, frames=3)
+    assert lib.ca_tattn_fused(C.byref(bad), None) < 0 and b"ca_tattn_fused" in lib.ca_last_error()
+    for args in ((None, 960, 320, FAKE), (FAKE, 640, 320, FAKE), (FAKE, 960, 320, 0x10008)):
+        assert lib.ca_pack_w_tattn(args[0], args[1], args[2], args[3], None) < 0

@@ -737,3 +737,31 @@ def test_gemm_and_conv_256x320_streaming_kernel(dtype):
         rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
         assert torch.isfinite(outs[0].float()).all() and rel < tol, (name, rel)
         assert torch.equal(outs[0], outs[1]), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.2e-2)])
+def test_tattn_fused_c320(dt, tol):
+    """ca_tattn_fused (ABI v10): LayerNorm + positional encoding + q|k|v + attention over the 16 frames in one launch, against fp32
+    torch and against the two-launch path it replaces; the library's weight packing against layers.frag_order_tattn."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import tattn_check as T
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.layers import frag_order_tattn
+    for (b, tokens, lda) in [(2, 1024, 320), (1, 1032, 640)]:
+        x, w, gamma, beta, pe = T.make(b, tokens, dt, lda=lda)
+        ref = T.reference(x, w, gamma, beta, pe, b, tokens)
+        wl = torch.empty(368640, device="cuda", dtype=dt)
+        K.check(K.lib().ca_pack_w_tattn(w.data_ptr(), 960, 320, wl.data_ptr(), K._stream()), "ca_pack_w_tattn")
+        assert torch.equal(wl, frag_order_tattn(w.float()).to(dt))
+        o = T.fused(x, w, gamma, beta, pe, b, tokens, wl)
+        assert o is not None, "the library must take this shape"
+        assert torch.equal(o, T.fused(x, w, gamma, beta, pe, b, tokens, wl))
+        rel = ((o.float() - ref).norm() / ref.norm()).item()
+        old = T.two_launch(x, w, gamma, beta, pe, b, tokens)
+        rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+        assert rel < tol and rel < 1.5 * rel_old + 1e-4, (rel, rel_old)
+    # shapes the kernel does not implement are declined, not mis-run
+    x, w, gamma, beta, pe = T.make(1, 64, dt)   # 1024 rows: too few
+    assert T.fused(x, w, gamma, beta, pe, 1, 64) is None
