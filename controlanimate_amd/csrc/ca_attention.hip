@@ -751,9 +751,227 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Text cross-attention (round 4): nk = 77 keys, 8 heads of 40 / 80, thousands of queries per image.
+//
+// The generic kernel above gives a block 128 queries of ONE head and stages K / V through LDS per block: 8192 blocks at the
+// 64x64-latent level, each a chain of dependent global round trips (Q, K/V tile 0, K/V tile 1, epilogue) around a few hundred
+// MFMAs -- 100 us for 168 MB (64x64 latents), 107 us for 84 MB (32x32): latency, not bandwidth.  Here:
+//   * a block is 8 waves = the 8 HEADS of the same query rows (every 128-byte line of q and o is used whole while it is hot);
+//   * K and V of the wave's head live in REGISTERS for the whole launch (77 keys: five 16-key tiles): K as A fragments
+//     pre-multiplied by scale * log2(e), V as V^T A fragments gathered once with the key order of a 32-key chunk permuted to
+//     the order the S^T accumulators hold it (keys 4g + r of tile 2c, then of tile 2c + 1) -- no LDS, no barriers, waves free;
+//   * a block walks QC query tiles per item (persistent over items, K / V reloaded only when the text batch changes), Q
+//     fragments two tiles ahead;
+//   * per 16-query tile: S^T = K Q^T (16x16x32 + one 16x16x16 for d = 32..39 / 64..79), one max / exp2 / sum over the
+//     lane's 20 scores (two v_permlane swaps each for the four row groups), O^T = V^T P^T, 8-byte stores.
+template <int DT, int D, int QC>
+__global__ __launch_bounds__(512, 2) void k_attn_short(AttnKParams p, int chunks, int items) {
+  constexpr int C32 = D / 32;        // full 32-deep chunks of the head dimension (1, 2); the rest (8 / 16 wide) is one 16-deep chunk
+  constexpr int DV = (D + 15) / 16;  // d_v tiles (3, 5)
+  constexpr int KT = 5;              // 16-key tiles: nk <= 80
+  constexpr unsigned OOB_V = 0x80000000u;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int head = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+
+  u32x4 kf[KT][C32], vf[DV][2];
+  u32x2 kf16[KT], vf16[DV];
+  int cur_zk = -1;
+
+  const int per = (items + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int i0 = (int)blockIdx.x * per, i1 = i0 + per < items ? i0 + per : items;
+  for (int item = i0; item < i1; ++item) {
+    const int z = item / chunks, ch = item - z * chunks;
+    const int zo = z / p.inner_count, zi = z - zo * p.inner_count;
+    const int zk = (z / p.kv_div) % p.kv_mod;
+    if (zk != cur_zk) {  // (block-uniform)
+      cur_zk = zk;
+      const int zko = zk / p.kv_inner_count, zki = zk - zko * p.kv_inner_count;
+      const int64_t kvoff = zko * p.k_outer + zki * p.k_inner + (int64_t)head * D;
+      const u16* kp = p.k + kvoff;
+      const u16* vp = p.v + kvoff;
+      const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int key = kt * 16 + l15;
+#pragma unroll
+        for (int c = 0; c < C32; ++c) {
+          u32x4 v = key < p.nk ? ld16(kp + (int64_t)key * p.k_row + c * 32 + g * 8) : zero4;
+          float f[8];
+          unpack8<DT>(v, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] *= p.scale_log2;
+          kf[kt][c] = pack8<DT>(f);
+        }
+        const int d16 = C32 * 32 + g * 4;
+        u32x2 w = {0u, 0u};
+        if (key < p.nk && d16 < D) w = *reinterpret_cast<const u32x2*>(kp + (int64_t)key * p.k_row + d16);
+        kf16[kt] = (u32x2){pack2<DT>(Elem<DT>::to_f((u16)(w[0] & 0xffffu)) * p.scale_log2, Elem<DT>::to_f((u16)(w[0] >> 16)) * p.scale_log2),
+                           pack2<DT>(Elem<DT>::to_f((u16)(w[1] & 0xffffu)) * p.scale_log2, Elem<DT>::to_f((u16)(w[1] >> 16)) * p.scale_log2)};
+      }
+      // V^T fragments: row d_v = 16 j + l15; k-slot e of 32-key chunk c is key 32 c + 4 g + e (e < 4) / 32 c + 16 + 4 g + (e - 4)
+#pragma unroll
+      for (int j = 0; j < DV; ++j) {
+        const int dv = 16 * j + l15;
+        const bool dok = dv < D;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          unsigned w[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const int k0 = 32 * c + (e2 >> 1) * 16 + 4 * g + (e2 & 1) * 2;
+            const unsigned a = (dok && k0 < p.nk) ? (unsigned)vp[(int64_t)k0 * p.k_row + dv] : 0u;
+            const unsigned b = (dok && k0 + 1 < p.nk) ? (unsigned)vp[(int64_t)(k0 + 1) * p.k_row + dv] : 0u;
+            w[e2] = a | (b << 16);
+          }
+          vf[j][c] = (u32x4){w[0], w[1], w[2], w[3]};
+        }
+        unsigned w2[2];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          const int k0 = 64 + 4 * g + 2 * e2;
+          const unsigned a = (dok && k0 < p.nk) ? (unsigned)vp[(int64_t)k0 * p.k_row + dv] : 0u;
+          const unsigned b = (dok && k0 + 1 < p.nk) ? (unsigned)vp[(int64_t)(k0 + 1) * p.k_row + dv] : 0u;
+          w2[e2] = a | (b << 16);
+        }
+        vf16[j] = (u32x2){w2[0], w2[1]};
+      }
+    }
+
+    const u16* qp = p.q + zo * p.q_outer + zi * p.q_inner + (int64_t)head * D;
+    u16* op = p.o + zo * p.o_outer + zi * p.o_inner + (int64_t)head * D;
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)qp, 0, (unsigned)(((int64_t)(p.nq - 1) * p.q_row + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)op, 0, (unsigned)(((int64_t)(p.nq - 1) * p.o_row + D) * 2), 0x00020000);
+    const int t0 = ch * QC;
+    u32x4 qf[3][C32];
+    u32x2 qf16[3];
+    auto q_load = [&](int tt, int buf) __attribute__((always_inline)) {
+      const int qi = (t0 + tt) * 16 + l15;
+      const unsigned ro = qi < p.nq ? (unsigned)qi * (unsigned)p.q_row * 2u : OOB_V;
+#pragma unroll
+      for (int c = 0; c < C32; ++c) qf[buf][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, ro + (unsigned)(c * 32 + g * 8) * 2u, 0, 0));
+      const int d16 = C32 * 32 + g * 4;
+      qf16[buf] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_q, d16 < D ? ro + (unsigned)d16 * 2u : OOB_V, 0, 0));
+    };
+    q_load(0, 0);
+    q_load(1, 1);
+#pragma unroll
+    for (int tt = 0; tt < QC; ++tt) {
+      const int buf = tt % 3;
+      if (tt + 2 < QC) q_load(tt + 2, (tt + 2) % 3);
+      if ((t0 + tt) * 16 >= p.nq) continue;  // (wave-uniform)
+      // Dependent MFMAs of DIFFERENT shapes are kept whole groups apart (sched_barrier pins the order): hipcc places too few wait
+      // states between a 16x16x16 and a 16x16x32 that accumulates onto it -- rows 2, 3 of the small one's result arrived after
+      // the big one had read them (measured: d_v = 2, 3 mod 4 of every output lost the keys 64.. and kept the previous tile's sum).
+      f32x4 s[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) s[kt] = Elem<DT>::mfma(kf[kt][0], qf[buf][0], (f32x4){0.f, 0.f, 0.f, 0.f});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 1; c < C32; ++c) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) s[kt] = Elem<DT>::mfma(kf[kt][c], qf[buf][c], s[kt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) s[kt] = Elem<DT>::mfma16(kf16[kt], qf16[buf], s[kt]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (64 + 4 * g + r >= p.nk) s[4][r] = -INFINITY;  // (64 < nk <= 80: only the last tile is ragged)
+      float m = vmax3(s[0][0], s[0][1], s[0][2]);
+      m = vmax3(m, s[0][3], s[1][0]);
+#pragma unroll
+      for (int kt = 1; kt < KT; ++kt) {
+        m = vmax3(m, s[kt][1], s[kt][2]);
+        if (kt + 1 < KT) m = vmax3(m, s[kt][3], s[kt + 1][0]);
+        else m = vmax2(m, s[kt][3]);
+      }
+      m = rowgroup_max(m);
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m);
+          l += s[kt][r];
+        }
+      const float inv = p.out_scale * __builtin_amdgcn_rcpf(rowgroup_sum(l));
+      u32x4 pf[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        pf[c] = (u32x4){pack2_prob<DT>(s[2 * c][0], s[2 * c][1]), pack2_prob<DT>(s[2 * c][2], s[2 * c][3]), pack2_prob<DT>(s[2 * c + 1][0], s[2 * c + 1][1]),
+                        pack2_prob<DT>(s[2 * c + 1][2], s[2 * c + 1][3])};
+      const u32x2 p16 = {pack2_prob<DT>(s[4][0], s[4][1]), pack2_prob<DT>(s[4][2], s[4][3])};
+      const int qi = (t0 + tt) * 16 + l15;
+      const unsigned ro = qi < p.nq ? (unsigned)qi * (unsigned)p.o_row * 2u : OOB_V;
+      f32x4 o[DV];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < DV; ++j) o[j] = Elem<DT>::mfma(vf[j][0], pf[0], (f32x4){0.f, 0.f, 0.f, 0.f});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < DV; ++j) o[j] = Elem<DT>::mfma(vf[j][1], pf[1], o[j]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < DV; ++j) o[j] = Elem<DT>::mfma16(vf16[j], p16, o[j]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < DV; ++j) {
+        const int dv = 16 * j + 4 * g;
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack2<DT>(o[j][0] * inv, o[j][1] * inv), pack2<DT>(o[j][2] * inv, o[j][3] * inv)}, rs_o,
+                                              dv < D ? ro + (unsigned)dv * 2u : OOB_V, 0, 0);
+      }
+    }
+  }
+}
+
+// 1: this launch is the text cross-attention k_attn_short takes
+static bool attn_short_eligible(const AttnKParams& p) {
+  static const int env = CA_KNOB("CA_ATTN_SHORT", 1);
+  if (!env) return false;
+  if (p.heads != 8 || (p.head_dim != 40 && p.head_dim != 80)) return false;
+  if (p.nk <= 64 || p.nk > 80 || p.nq < 256 || p.accumulate || p.causal || p.key_mask) return false;
+  if (p.q_row % 8 || p.o_row % 4 || p.k_row % 4) return false;
+  const int64_t lim = 0x7FFFFF00ll;
+  return ((int64_t)(p.nq - 1) * p.q_row + p.head_dim) * 2 < lim && ((int64_t)(p.nq - 1) * p.o_row + p.head_dim) * 2 < lim;
+}
+
+template <int DT>
+static void launch_attn_short(const AttnKParams& p, hipStream_t st) {
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  static int cu_cached = 0;
+  if (!cu_cached) {
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    cu_cached = cus;
+  }
+  cus = cu_cached;
+  const int qtiles = ceil_div_i(p.nq, 16);
+  // query tiles per item: whole items per block, about one item per CU or more
+  const int qc = (int64_t)p.batches * ceil_div_i(qtiles, 16) >= cus ? 16 : 8;
+  const int chunks = ceil_div_i(qtiles, qc);
+  const int items = p.batches * chunks;
+  const unsigned grid = (unsigned)(items < cus ? items : cus);
+  if (p.head_dim == 40) {
+    if (qc == 16) hipLaunchKernelGGL((k_attn_short<DT, 40, 16>), dim3(grid), dim3(512), 0, st, p, chunks, items);
+    else hipLaunchKernelGGL((k_attn_short<DT, 40, 8>), dim3(grid), dim3(512), 0, st, p, chunks, items);
+  } else {
+    if (qc == 16) hipLaunchKernelGGL((k_attn_short<DT, 80, 16>), dim3(grid), dim3(512), 0, st, p, chunks, items);
+    else hipLaunchKernelGGL((k_attn_short<DT, 80, 8>), dim3(grid), dim3(512), 0, st, p, chunks, items);
+  }
+}
+
 template <int DT>
 int launch_attn(const AttnKParams& p, hipStream_t st) {
   const int d = p.head_dim;
+  if (attn_short_eligible(p)) {
+    launch_attn_short<DT>(p, st);
+    return CA_OK;
+  }
   if (d <= 32) launch_attn_d<DT, 1, 2>(p, st);
   else if (d <= 48) launch_attn_d<DT, 2, 3>(p, st);
   else if (d <= 64) launch_attn_d<DT, 2, 4>(p, st);

@@ -407,7 +407,9 @@ def test_attention_online_softmax_rescale():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("b,f,tokens,heads,d,L,strip", [(2, 4, 64, 8, 40, 77, 0), (1, 3, 50, 8, 80, 81, 4), (2, 2, 16, 8, 160, 77, 0)])
+@pytest.mark.parametrize("b,f,tokens,heads,d,L,strip", [(2, 4, 64, 8, 40, 77, 0), (1, 3, 50, 8, 80, 81, 4), (2, 2, 16, 8, 160, 77, 0),
+                                                    # (>= 256 queries, 65..80 keys, 8 heads of 40 / 80: the register-resident K/V kernel k_attn_short)
+                                                    (2, 3, 300, 8, 40, 77, 0), (1, 3, 272, 8, 80, 81, 4), (3, 2, 1000, 8, 80, 70, 0), (2, 16, 256, 8, 40, 80, 0)])
 def test_attention_cross_and_ip(b, f, tokens, heads, d, L, strip, dtype):
     k = _k()
     c = heads * d
