@@ -3,8 +3,8 @@
 // (reference: animatediff/models/motion_module.py:251-331 VersatileAttention.forward -- norm, positional encoding, to_q / to_k /
 // to_v, attention over the frame axis; the output projection + residual stays a ca_gemm call).
 //
-// Why: as separate launches the 131072 x 960 q|k|v tensor is written (252 MB, the activation-resident GEMM is bound by exactly that
-// store: 125 us) and read back by an attention kernel whose whole arithmetic is 16 x 16 scores per (pixel, head) (125 us of strided
+// Why: as separate launches the 131072 x 960 q|k|v tensor is written (252 MB: the activation-resident GEMM cannot hide that store
+// phase, 125 us) and read back by an attention kernel whose whole arithmetic is 16 x 16 scores per (pixel, head) (125 us of strided
 // 80-byte pieces).  The sequence a (pixel, head) attends over is 16 rows -- ONE MFMA row tile -- so a block that holds the 16 frames
 // of 8 pixels as its 128-row tile can finish the attention in registers and write only o (84 MB).
 //
