@@ -25,7 +25,7 @@ def cases(dt, small=False):
     rn = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev)
     out = []
     for (m, n) in ([(16384 + 8, 960), (20480, 960), (16384 + 200, 2560), (16384, 1280)] if small else
-                   [(16384 + 8, 960), (131072, 960), (16384 + 200, 2560), (32768, 1280), (20000, 320)]):
+                   [(16384 + 8, 960), (131072, 960), (16384 + 200, 2560), (32768, 1280), (20000, 320), (131072, 320), (16384 + 8, 320)]):
         k = 320
         a = rn(m, k).to(dt)
         w = rn(n, k, scale=k ** -0.5).to(dt)
@@ -98,23 +98,31 @@ def check():
             same = all(torch.equal(outs[0], o) for o in outs[1:])
             nd = (outs[0] != old).float().mean().item()
             tol = 2e-3 if dt == torch.float16 else 1.2e-2
-            ok = rel < tol and same and torch.isfinite(outs[0].float()).all() and (lab == "ar128x64" or (lab == "wres160" and kw["w"].shape[0] < 960))
+            want = "ar128x64" if kw["w"].shape[0] >= 960 else "wres160"
+            ok = rel < tol and same and torch.isfinite(outs[0].float()).all() and lab == want
             bad += not ok
             print(f"{str(dt)[6:]:9s} {name:36s} {lab:9s} rel {rel:.2e} (was {lab_old} {rel_old:.2e}) differing elements {nd:.2e} deterministic={same}{'' if ok else '   <<<<<< FAIL'}", flush=True)
     return bad
 
 
-def timeit(fn, it=20):
+def timeit(fn, it=10):
+    """us per call inside a hipGraph (no host launch gaps: the N = 320 launches are shorter than a Python call)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(it):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(it):
-        fn()
+    for _ in range(3):
+        g.replay()
     e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / it * 1e3
+    return s.elapsed_time(e) / (3 * it) * 1e3
 
 
 def timing():
