@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CA_HIP_LIB") or os.path.join(_HERE, "csrc", "libcontr
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class CAHipUnavailable(RuntimeError):
@@ -60,6 +60,20 @@ class TattnArgs(C.Structure):
 
 
 TATTN_W_FRAG_ELEMS = 368640  # CA_TATTN_W_FRAG_ELEMS
+
+
+class XattnArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("wq_frag", C.c_void_p), ("bias", C.c_void_p), ("kv_frag", C.c_void_p), ("o", C.c_void_p),
+        ("lda", C.c_int64), ("ldo", C.c_int64),
+        ("m", C.c_int32), ("tokens", C.c_int32), ("frames_per_kv", C.c_int32), ("kv_mod", C.c_int32), ("kv_batches", C.c_int32),
+        ("nk", C.c_int32), ("heads", C.c_int32), ("c", C.c_int32),
+        ("ln_eps", C.c_float), ("dtype", C.c_int32),
+    ]
+
+
+XATTN_W_FRAG_ELEMS = 122880   # CA_XATTN_W_FRAG_ELEMS
+XATTN_KV_FRAG_ELEMS = 7680    # CA_XATTN_KV_FRAG_ELEMS, per (text batch, head)
 
 
 class ConvArgs(C.Structure):
@@ -124,6 +138,10 @@ SYMBOLS = {
     "ca_tattn_fused": (C.c_int, [C.POINTER(TattnArgs), C.c_void_p]),
     "ca_tattn_fused_supported": (C.c_int, [C.POINTER(TattnArgs)]),
     "ca_pack_w_tattn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ca_xattn_fused": (C.c_int, [C.POINTER(XattnArgs), C.c_void_p]),
+    "ca_xattn_fused_supported": (C.c_int, [C.POINTER(XattnArgs)]),
+    "ca_xattn_pack_w": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ca_xattn_pack_kv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "ca_gemm_ln_inline_supported": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_gemm_wants_finished_stats": (C.c_int, [C.POINTER(GemmArgs)]),
     "ca_ln_finish_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

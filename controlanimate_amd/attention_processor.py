@@ -52,6 +52,25 @@ class AttnProcessor2_0(nn.Module):
             if o is not None:
                 out = attn.to_out[0].run(o, residual=res, row_sums=row_sums)
                 return K.carry_row_sums(out.reshape(B, N, C), out)
+        if (ln is not None and encoder_hidden_states is not None and cache is not None and getattr(attn, "xfrag", None) is not None
+                and type(self).ip_branch is AttnProcessor2_0.ip_branch):
+            # LayerNorm + to_q + attention over the text tokens in one launch where the library takes the shape (processors that need q
+            # again -- the IP-Adapter's second attention -- keep the separate launches).  The K / V fragments are packed once per
+            # window beside the projected K / V (refresh_window_caches repacks them in place).
+            ctx = encoder_hidden_states
+            nb, L, cd = ctx.shape
+            nk = L - self.num_tokens
+            kv = cache.get(("kv", id(attn)))
+            if kv is None:
+                kv = cache[("kv", id(attn))] = K.gemm(ctx.reshape(nb * L, cd), attn.kv.t)
+            ent = cache.get(("kvf", id(attn)))
+            if ent is None:
+                ent = cache[("kvf", id(attn))] = (K.xattn_pack_kv(kv, nb, L, nk, attn.scale), nk, L)
+            if ent[0] is not None and ent[1] == nk:
+                o = K.xattn_fused(x, attn.xfrag.t, ln[1].b.t, ent[0], B, N, frames_per_kv, kv_mod, nk, ln[1].eps)
+                if o is not None:
+                    out = attn.to_out[0].run(o, residual=res, row_sums=row_sums)
+                    return K.carry_row_sums(out.reshape(B, N, C), out)
         if ln is not None:
             st, fold = ln
             if encoder_hidden_states is None and temporal is not None and fold.pe is not None:
@@ -171,6 +190,12 @@ class Attention(nn.Module):
             self.fold = LnFold(arena, dtype, fold_ln, [self.to_q] if self.is_cross else [self.to_q, self.to_k, self.to_v], pe=pe)
             if self.is_cross:
                 self.kv = pack_concat_rows(arena, dtype, [self.to_k, self.to_v])
+                # the one-launch form of LayerNorm + to_q + attention over the text tokens (K.xattn_fused: C = 320, 8 heads of 40)
+                self.xfrag = None
+                if (self.heads, self.inner_dim, self.query_dim) == (8, 320, 320):
+                    from .layers import frag_order_xattn
+                    fold = self.fold
+                    self.xfrag = arena.add((122880,), dtype, lambda: frag_order_xattn(fold.w_fold().to(dtype).float()))
         elif self.is_cross:
             self.to_q.pack(arena, dtype)
             self.kv = pack_concat_rows(arena, dtype, [self.to_k, self.to_v])

@@ -6,6 +6,7 @@ using namespace ca_gemm_detail;
 #include "ca_gemm_ar.h"
 #include "ca_ff_fused.h"
 #include "ca_tattn_fused.h"
+#include "ca_xattn_fused.h"
 
 int ar_cu_count() {
   static int n = 0;
@@ -149,6 +150,69 @@ extern "C" int ca_tattn_fused(const ca_tattn_args* a, void* stream) {
   if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_tattn_fused<CA_BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles);
   else hipLaunchKernelGGL((k_tattn_fused<CA_F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles);
   CA_CHECK_LAUNCH("ca_tattn_fused");
+  return CA_OK;
+}
+
+extern "C" int ca_xattn_pack_w(const void* w, int32_t n, int32_t k, void* dst, void* stream) {
+  CA_REQUIRE(w && dst, "ca_xattn_pack_w: null operand");
+  CA_REQUIRE(n == 320 && k == 320, "ca_xattn_pack_w: n=%d k=%d (Wq: 320 x 320)", n, k);
+  CA_REQUIRE((((uintptr_t)w | (uintptr_t)dst) & 15) == 0, "ca_xattn_pack_w: operands must be 16-byte aligned");
+  static_assert(CA_XATTN_WF_ELEMS == CA_XATTN_W_FRAG_ELEMS && CA_XATTN_KVF_ELEMS == CA_XATTN_KV_FRAG_ELEMS, "header constants");
+  hipLaunchKernelGGL(k_xattn_pack_w, dim3((CA_XATTN_WF_ELEMS / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u16*)w, (u16*)dst);
+  CA_CHECK_LAUNCH("ca_xattn_pack_w");
+  return CA_OK;
+}
+
+extern "C" int ca_xattn_pack_kv(const void* kv, int64_t ld, int32_t kv_batches, int32_t rows_per_batch, int32_t row_offset, int32_t nk, float scale, int32_t dtype,
+                                void* dst, void* stream) {
+  CA_REQUIRE(kv && dst, "ca_xattn_pack_kv: null operand");
+  CA_REQUIRE(kv_batches > 0 && rows_per_batch > 0 && row_offset >= 0 && nk > 64 && nk <= 80 && row_offset + nk <= rows_per_batch && ld >= 640,
+             "ca_xattn_pack_kv: kv_batches=%d rows_per_batch=%d row_offset=%d nk=%d (65..80) ld=%lld (>= 640: K | V of 8 heads x 40)", kv_batches, rows_per_batch, row_offset, nk,
+             (long long)ld);
+  CA_REQUIRE(dtype == CA_BF16 || dtype == CA_F16, "ca_xattn_pack_kv: dtype %d", dtype);
+  CA_REQUIRE(((uintptr_t)dst & 15) == 0 && scale > 0.f, "ca_xattn_pack_kv: dst must be 16-byte aligned, scale > 0");
+  const float sl2 = scale * 1.4426950408889634f;
+  if (dtype == CA_BF16) hipLaunchKernelGGL((k_xattn_pack_kv<CA_BF16>), dim3((unsigned)kv_batches * 8), dim3(64), 0, (hipStream_t)stream, (const u16*)kv, ld, rows_per_batch, row_offset, nk, sl2, (u16*)dst);
+  else hipLaunchKernelGGL((k_xattn_pack_kv<CA_F16>), dim3((unsigned)kv_batches * 8), dim3(64), 0, (hipStream_t)stream, (const u16*)kv, ld, rows_per_batch, row_offset, nk, sl2, (u16*)dst);
+  CA_CHECK_LAUNCH("ca_xattn_pack_kv");
+  return CA_OK;
+}
+
+extern "C" int ca_xattn_fused_supported(const ca_xattn_args* a) {
+  if (!a || !a->x || !a->wq_frag || !a->kv_frag || !a->o) return 0;
+  if (a->c != 320 || a->heads != 8 || a->m < 16384 || a->tokens < 128 || a->tokens % 128 || a->m % a->tokens) return 0;
+  if (a->nk <= 64 || a->nk > 80 || a->frames_per_kv < 1 || a->kv_mod < 1 || a->kv_batches < a->kv_mod) return 0;
+  if (a->dtype != CA_BF16 && a->dtype != CA_F16) return 0;
+  if (a->lda % 8 || a->ldo % 8 || a->lda < 320 || a->ldo < 320) return 0;
+  if ((((uintptr_t)a->x | (uintptr_t)a->o | (uintptr_t)a->wq_frag | (uintptr_t)a->kv_frag | (uintptr_t)a->bias) & 15) != 0) return 0;
+  const int64_t lim = 0x7FFFFF00ll;
+  if (((int64_t)(a->m - 1) * a->lda + 320) * 2 >= lim || ((int64_t)(a->m - 1) * a->ldo + 320) * 2 >= lim) return 0;
+  if (!(a->ln_eps > 0.f)) return 0;
+  return 1;
+}
+
+extern "C" int ca_xattn_fused(const ca_xattn_args* a, void* stream) {
+  CA_REQUIRE(a != nullptr, "ca_xattn_fused: null args");
+  CA_REQUIRE(ca_xattn_fused_supported(a), "ca_xattn_fused: arguments outside what the fused text cross-attention takes (C = 320, 8 heads, 65..80 keys, tokens %% 128 == 0, "
+                                           ">= 16384 rows, packed weights and K / V, 16-byte aligned operands, 32-bit byte offsets): ask ca_xattn_fused_supported() first");
+  XattnParams p{};
+  p.x = (const u16*)a->x;
+  p.wf = (const u16*)a->wq_frag;
+  p.bias = a->bias;
+  p.kvf = (const u16*)a->kv_frag;
+  p.o = (u16*)a->o;
+  p.lda = (int)a->lda, p.ldo = (int)a->ldo;
+  p.m = a->m, p.tokens = a->tokens, p.frames_per_kv = a->frames_per_kv, p.kv_mod = a->kv_mod, p.nk = a->nk;
+  p.ln_eps = a->ln_eps;
+  p.x_bytes = (unsigned)(((int64_t)(a->m - 1) * a->lda + 320) * 2);
+  p.o_bytes = (unsigned)(((int64_t)(a->m - 1) * a->ldo + 320) * 2);
+  p.kvf_bytes = (unsigned)((int64_t)a->kv_batches * 8 * CA_XATTN_KVF_ELEMS * 2);
+  const int tiles = a->m / 128;
+  const int slots = 2 * ar_cu_count();
+  const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+  if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_xattn_fused<CA_BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles);
+  else hipLaunchKernelGGL((k_xattn_fused<CA_F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles);
+  CA_CHECK_LAUNCH("ca_xattn_fused");
   return CA_OK;
 }
 

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import (AttnArgs, ConvArgs, FfArgs, TattnArgs, GemmArgs, GroupNormArgs, LayerNormArgs, CA_ACT_NONE,
+from ._capi import (AttnArgs, ConvArgs, FfArgs, TattnArgs, XattnArgs, GemmArgs, GroupNormArgs, LayerNormArgs, CA_ACT_NONE,
                     CA_ACT_SILU, CA_BF16, CA_F16, check, lib)
 
 ACT_NONE, ACT_SILU = CA_ACT_NONE, CA_ACT_SILU
@@ -199,6 +199,46 @@ def tattn_fused(x: torch.Tensor, w_frag: torch.Tensor, gamma: torch.Tensor, bias
     if _plan_sink is not None:
         _plan_sink.append("tattn_fused128")
     check(lib().ca_tattn_fused(C.byref(args), _stream()), "ca_tattn_fused")
+    return o
+
+
+_XATTN_FUSED_ON = os.environ.get("CA_XATTN_FUSED", "1") != "0"  # (0: text cross-attention always as q GEMM + attention -- A/B runs)
+
+
+def xattn_pack_kv(kv: torch.Tensor, kv_batches: int, rows_per_batch: int, nk: int, scale: float, row_offset: int = 0,
+                  out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """The K | V rows of `kv` [kv_batches * rows_per_batch, 2 * 320] as the MFMA fragments ca_xattn_fused reads (ca_xattn_pack_kv,
+    ABI v11; once per window and layer) -- or None for shapes the fused kernel does not take."""
+    if not _XATTN_FUSED_ON or kv.dim() != 2 or kv.shape[1] != 640 or kv.stride(1) != 1 or not (64 < nk <= 80) or kv.dtype not in (torch.float16, torch.bfloat16):
+        return None
+    _req_cuda(kv)
+    dst = out if out is not None else torch.empty((kv_batches, 8, _capi.XATTN_KV_FRAG_ELEMS), device=kv.device, dtype=kv.dtype)
+    assert dst.shape == (kv_batches, 8, _capi.XATTN_KV_FRAG_ELEMS) and dst.dtype == kv.dtype and dst.is_contiguous()
+    check(lib().ca_xattn_pack_kv(kv.data_ptr(), kv.stride(0), kv_batches, rows_per_batch, row_offset, nk, float(scale), dt_code(kv.dtype),
+                                 dst.data_ptr(), _stream()), "ca_xattn_pack_kv")
+    return dst
+
+
+def xattn_fused(x: torch.Tensor, wq_frag: torch.Tensor, bias: Optional[torch.Tensor], kv_frag: torch.Tensor, images: int, tokens: int,
+                frames_per_kv: int, kv_mod: int, nk: int, ln_eps: float) -> Optional[torch.Tensor]:
+    """o = softmax(q K^T scale) V with q = LayerNorm(x) Wq^T + bias in one launch (ca_xattn_fused, ABI v11: the text cross-attention of
+    the 64x64-latent level) -- or None where the library does not take the arguments (the caller then runs the folded q GEMM and
+    attention_cross).  kv_frag from xattn_pack_kv; image z uses its text batch (z // frames_per_kv) % kv_mod."""
+    if not _XATTN_FUSED_ON or kv_frag is None:
+        return None
+    _req_cuda(x, wq_frag, bias, kv_frag)
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[0] != images * tokens:
+        return None
+    c = x.shape[1]
+    o = torch.empty((x.shape[0], c), device=x.device, dtype=x.dtype)
+    args = XattnArgs(x=_p(x), wq_frag=_p(wq_frag), bias=_p(bias), kv_frag=_p(kv_frag), o=_p(o), lda=x.stride(0), ldo=o.stride(0), m=x.shape[0],
+                     tokens=tokens, frames_per_kv=frames_per_kv, kv_mod=kv_mod if kv_mod > 0 else kv_frag.shape[0], kv_batches=kv_frag.shape[0],
+                     nk=nk, heads=8, c=c, ln_eps=float(ln_eps), dtype=dt_code(x.dtype))
+    if not lib().ca_xattn_fused_supported(C.byref(args)):
+        return None
+    if _plan_sink is not None:
+        _plan_sink.append("xattn_fused128")
+    check(lib().ca_xattn_fused(C.byref(args), _stream()), "ca_xattn_fused")
     return o
 
 

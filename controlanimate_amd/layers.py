@@ -121,6 +121,17 @@ def frag_order_tattn(wqkv: torch.Tensor) -> torch.Tensor:
     return x.permute(2, 1, 0, 5, 3, 6, 4, 7).reshape(-1).contiguous()  # [wv, hi, ps, kq, j, g, i, e]
 
 
+def frag_order_xattn(wq: torch.Tensor) -> torch.Tensor:
+    """[320, 320] (Wq of 8 heads x 40, LayerNorm-folded) -> the flat order ca_xattn_args.wq_frag takes (= ca_xattn_pack_w,
+    csrc/ca_xattn_fused.h): 16-byte piece L of column tile j of 32-deep chunk kq of head wv + 4 hi holds
+    Wq[head * 40 + 16 j + (L & 15)][kq * 32 + (L >> 4) * 8 : + 8], zeros where 16 j + (L & 15) >= 40."""
+    assert tuple(wq.shape) == (320, 320)
+    wpad = wq.new_zeros(8, 48, 320)
+    wpad[:, :40] = wq.view(8, 40, 320)
+    x = wpad.view(2, 4, 3, 16, 10, 4, 8)  # [hi, wv, j, i = L & 15, kq, g = L >> 4, e]
+    return x.permute(1, 0, 4, 2, 5, 3, 6).reshape(-1).contiguous()  # [wv, hi, kq, j, g, i, e]
+
+
 def frag_wanted(n: int, k: int) -> bool:
     """The shapes the activation-resident kernel takes (ca_gemm.hip ar_eligible): K = 320, N a multiple of 320, N >= 960."""
     return k == 320 and n % 320 == 0 and n >= 960
@@ -268,6 +279,7 @@ class LnFold:
             return geglu_interleave(b) if geglu else b
 
         self.w = arena.add((n, k), dtype, w_fold)
+        self.w_fold = w_fold  # (the fp32 folded weight: other packings of it -- attention_processor.Attention.pack)
         if frag_wanted(n, k):
             self.w.frag = (arena.add((n, k), dtype, lambda: frag_order(w_fold(), geglu)), geglu)
         self.cs = arena.add((n,), torch.float32, lambda: w_fold().to(dtype).float().sum(1))

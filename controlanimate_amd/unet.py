@@ -133,6 +133,9 @@ class HipModelMixin:
             if kv is not None and hasattr(m, "kv"):
                 K.gemm(ehs.reshape(nb * L, cd), m.kv.t, out=kv)
                 n += 1
+                ent = cache.get(("kvf", id(m)))  # the same K / V as MFMA fragments (K.xattn_fused)
+                if ent is not None and ent[0] is not None:
+                    K.xattn_pack_kv(kv, nb, ent[2], ent[1], m.scale, out=ent[0])
         for proc in (getattr(self, "attn_processors", None) or {}).values():
             kvip = cache.get(("kv_ip", id(proc)))
             if kvip is not None:

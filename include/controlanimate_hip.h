@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 10
+#define CA_ABI_VERSION 11
 
 /* element types */
 #define CA_BF16 0
@@ -189,6 +189,35 @@ int ca_tattn_fused_supported(const ca_tattn_args* args);
 /* dst[CA_TATTN_W_FRAG_ELEMS] = w[960, 320] (rows Wq, Wk, Wv) in the fragment order ca_tattn_args.w_frag takes (head dim 40
  * padded to 48 with zero rows; 16-bit elements, 16-byte aligned). */
 int ca_pack_w_tattn(const void* w, int32_t n, int32_t k, void* dst, void* stream);
+/* ABI v11: the text cross-attention of the 64x64-latent level up to (not including) its output projection,
+ *   o = softmax(q K^T * scale) V per (row, head),  q = LayerNorm(x) Wq^T + bias,  K / V = the projected text tokens of the row's batch element,
+ * in one launch (animatediff/models/attention.py:253-262: norm2, attn2.to_q, attention over encoder_hidden_states).  Row r belongs to
+ * image r / tokens; image z uses text batch (z / frames_per_kv) % kv_mod.  Takes c = 320, 8 heads of 40, 65..80 keys, tokens % 128 == 0,
+ * m >= 16384 and a multiple of tokens (ca_xattn_fused_supported: no launch, no device access); everything else runs as ca_gemm + ca_attention.
+ *   wq_frag: CA_XATTN_W_FRAG_ELEMS 16-bit elements written by ca_xattn_pack_w from the LayerNorm-FOLDED Wq (Wq diag(gamma));
+ *   bias [c] fp32 (Wq beta + b) or NULL;  kv_frag: kv_batches * 8 * CA_XATTN_KV_FRAG_ELEMS elements written by ca_xattn_pack_kv
+ *   (K pre-multiplied by scale * log2 e, once per window and layer). */
+#define CA_XATTN_W_FRAG_ELEMS 122880
+#define CA_XATTN_KV_FRAG_ELEMS 7680
+typedef struct ca_xattn_args {
+  const void* x;        /* [m, c] rows at stride lda */
+  const void* wq_frag;
+  const float* bias;
+  const void* kv_frag;
+  void* o;              /* [m, c] rows at stride ldo */
+  int64_t lda, ldo;
+  int32_t m, tokens, frames_per_kv, kv_mod, kv_batches, nk, heads, c;
+  float ln_eps;
+  int32_t dtype;
+} ca_xattn_args;
+int ca_xattn_fused(const ca_xattn_args* args, void* stream);
+int ca_xattn_fused_supported(const ca_xattn_args* args);
+/* dst[CA_XATTN_W_FRAG_ELEMS] = w[320, 320] in the per-head fragment order ca_xattn_args.wq_frag takes (head dim 40 padded to 48 with zero rows). */
+int ca_xattn_pack_w(const void* w, int32_t n, int32_t k, void* dst, void* stream);
+/* dst[kv_batches * 8 * CA_XATTN_KV_FRAG_ELEMS] = the K (columns 0..319, * scale * log2 e) and V (columns 320..639) rows
+ * row_offset .. row_offset + nk of every batch of kv [kv_batches * rows_per_batch, ld] as MFMA fragments in lane order. */
+int ca_xattn_pack_kv(const void* kv, int64_t ld, int32_t kv_batches, int32_t rows_per_batch, int32_t row_offset, int32_t nk, float scale, int32_t dtype,
+                     void* dst, void* stream);
 /* bytes of split-K scratch this launch can use (0: it would not split) */
 int64_t ca_gemm_workspace_bytes(const ca_gemm_args* args);
 /* partial sums per row this launch can leave in row_sums_out (0: it cannot).  N / 320 on the 128 x 320-tile kernels; ABI v8:

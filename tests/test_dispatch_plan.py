@@ -236,3 +236,26 @@ def test_fused_temporal_attention_only_takes_what_it_implements(capi):
     assert lib.ca_tattn_fused(C.byref(bad), None) < 0 and b"ca_tattn_fused" in lib.ca_last_error()
     for args in ((None, 960, 320, FAKE), (FAKE, 640, 320, FAKE), (FAKE, 960, 320, 0x10008)):
         assert lib.ca_pack_w_tattn(args[0], args[1], args[2], args[3], None) < 0
+
+
+def test_fused_text_cross_attention_only_takes_what_it_implements(capi):
+    """ABI v11 ca_xattn_fused_supported: C = 320, 8 heads, 65..80 keys, tokens % 128 == 0, >= 16384 rows, aligned operands."""
+    lib = capi.lib()
+
+    def ok(**over):
+        kw = dict(x=FAKE, wq_frag=FAKE, bias=FAKE, kv_frag=FAKE, o=FAKE, lda=320, ldo=320, m=131072, tokens=4096, frames_per_kv=16, kv_mod=2,
+                  kv_batches=2, nk=77, heads=8, c=320, ln_eps=1e-5, dtype=capi.CA_F16)
+        kw.update(over)
+        return lib.ca_xattn_fused_supported(C.byref(capi.XattnArgs(**kw)))
+
+    assert ok() == 1 and ok(dtype=capi.CA_BF16) == 1 and ok(bias=None) == 1 and ok(nk=80) == 1 and ok(m=16384, tokens=1024) == 1 and ok(lda=640) == 1
+    assert ok(nk=64) == 0 and ok(nk=81) == 0 and ok(heads=4) == 0 and ok(c=640) == 0 and ok(tokens=4100) == 0 and ok(m=131072 + 128) == 0
+    assert ok(m=8192, tokens=1024) == 0 and ok(kv_mod=3) == 0 and ok(frames_per_kv=0) == 0
+    assert ok(wq_frag=None) == 0 and ok(kv_frag=None) == 0 and ok(x=FAKE + 8) == 0 and ok(lda=324) == 0 and ok(ln_eps=0.0) == 0 and ok(dtype=7) == 0
+    assert ok(m=1 << 23, tokens=4096) == 0  # 32-bit byte offsets
+    bad = capi.XattnArgs(x=FAKE, m=5)
+    assert lib.ca_xattn_fused(C.byref(bad), None) < 0 and b"ca_xattn_fused" in lib.ca_last_error()
+    for args in ((None, 320, 320, FAKE), (FAKE, 640, 320, FAKE), (FAKE, 320, 320, 0x10008)):
+        assert lib.ca_xattn_pack_w(args[0], args[1], args[2], args[3], None) < 0
+    assert lib.ca_xattn_pack_kv(FAKE, 640, 2, 77, 0, 64, 0.158, capi.CA_F16, FAKE, None) < 0   # 64 keys: not this kernel's
+    assert lib.ca_xattn_pack_kv(FAKE, 640, 2, 77, 4, 77, 0.158, capi.CA_F16, FAKE, None) < 0   # rows beyond the batch

@@ -767,3 +767,41 @@ def test_tattn_fused_c320(dt, tol):
     # shapes the kernel does not implement are declined, not mis-run
     x, w, gamma, beta, pe = T.make(1, 64, dt)   # 1024 rows: too few
     assert T.fused(x, w, gamma, beta, pe, 1, 64) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.2e-2)])
+def test_xattn_fused_c320(dt, tol):
+    """ca_xattn_fused (ABI v11): LayerNorm + to_q + attention over the text tokens in one launch, against fp32 torch and against the
+    two launches it replaces; the library's packing kernels against layers.frag_order_xattn; K / V fragments repacked in place."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import xattn_check as X
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.layers import frag_order_xattn
+    for (images, tokens, L, nk, fpk, kvb, lda) in [(8, 2048, 77, 77, 4, 2, 320), (6, 3072, 81, 77, 2, 3, 640), (16, 1024, 70, 70, 8, 2, 320)]:
+        x, wq, gamma, beta, kv = X.make(images, tokens, L, kvb, dt, lda=lda)
+        ref = X.reference(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, dt)
+        wf, cs, bias = X.operands(x, wq, gamma, beta, dt)
+        wl = torch.empty(122880, device="cuda", dtype=dt)
+        K.check(K.lib().ca_xattn_pack_w(wf.data_ptr(), 320, 320, wl.data_ptr(), K._stream()), "ca_xattn_pack_w")
+        assert torch.equal(wl, frag_order_xattn(wf.float()).to(dt))
+        kvf = K.xattn_pack_kv(kv, kvb, L, nk, 40 ** -0.5)
+        o = X.fused(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, (wl, kvf))
+        assert o is not None, "the library must take this shape"
+        assert torch.equal(o, X.fused(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, (wl, kvf)))
+        rel = ((o.float() - ref).norm() / ref.norm()).item()
+        old = X.two_launch(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb)
+        rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+        assert rel < tol and rel < 1.5 * rel_old + 1e-4, (rel, rel_old)
+        # a new window: other K / V in the same buffers, fragments repacked in place
+        kv2 = X.make(images, tokens, L, kvb, dt, seed=9, lda=lda)[4]
+        kv.copy_(kv2)
+        assert K.xattn_pack_kv(kv, kvb, L, nk, 40 ** -0.5, out=kvf) is kvf
+        o2 = X.fused(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, (wl, kvf))
+        ref2 = X.reference(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, dt)
+        assert ((o2.float() - ref2).norm() / ref2.norm()).item() < tol
+    # declined, not mis-run: too few rows; 64 keys
+    x, wq, gamma, beta, kv = X.make(2, 1024, 77, 1, dt)
+    assert X.fused(x, wq, gamma, beta, kv, 2, 1024, 77, 77, 1, 1) is None
+    assert K.xattn_pack_kv(kv, 1, 77, 64, 40 ** -0.5) is None
