@@ -381,10 +381,16 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
 // on v_mfma_f32_16x16x16 (a lane holds k = 4g .. 4g+3: 8-byte fragment reads): QK^T costs 48 instead of 64 columns.
 template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool SR, bool FOLD, bool K16 = false>
 __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
-  constexpr int ROW = 64;                 // LDS row length (elements): head_dim <= 64
+  // LDS row length (elements): 64 for head dims up to 64; 128 for 65..80 (two 32-deep chunks + the 16-deep one: SD1.5's d = 80 with
+  // no padding at all -- round 4: the 1024-token self-attention of the 32x32-latent level ran on the generic kernel at 170 us)
+  constexpr int ROW = (DK32 * 32 + (K16 ? 16 : 0)) > 64 ? 128 : 64;
+  constexpr int CPR = ROW / 8;            // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;           // rows one wave-wide DMA instruction covers (8 / 4)
+  // chunk swizzle, conflict-free for ds_read_b128's 16-lane groups: 128-byte rows (row >> 1) & 7, 256-byte rows row & 15
+  auto swz = [](int row) { return ROW == 64 ? ((row >> 1) & 7) : (row & 15); };
   constexpr int KT = KB / 16, KC = KB / 32;
   constexpr int TILE = 2 * KB * ROW;      // K tile + V tile
-  constexpr int GRP = KB / 8 / NW;        // 8-row DMA groups per wave per operand
+  constexpr int GRP = KB / RPI / NW;      // DMA instructions per wave per operand and tile
   __shared__ __attribute__((aligned(16))) u16 smem[2 * TILE];
 
   const int tid = threadIdx.x;
@@ -424,8 +430,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
     const int cs = p.head_dim >> 3;
     for (int i = tid; i < 2 * KB; i += NW * 64) {
       const int buf = i / KB, r = i - buf * KB;
-      st16(smem + buf * TILE + KB * ROW + r * ROW + ((cs ^ ((r >> 1) & 7)) << 3), ones4);
-      if (FOLD) smem[buf * TILE + r * ROW + ((cs ^ ((r >> 1) & 7)) << 3)] = (u16)(one2 & 0xffffu);  // K[r][head_dim] = 1
+      st16(smem + buf * TILE + KB * ROW + r * ROW + ((cs ^ swz(r)) << 3), ones4);
+      if (FOLD) smem[buf * TILE + r * ROW + ((cs ^ swz(r)) << 3)] = (u16)(one2 & 0xffffu);  // K[r][head_dim] = 1
     }
   }
 
@@ -473,14 +479,14 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   };
 
   // DMA lane assignment: 8 rows x 8 chunks per wave instruction
-  const int r8 = lane >> 3, cpos = lane & 7;
+  const int r8 = lane / CPR, cpos = lane % CPR;
   int d_row[GRP];
   unsigned d_off[GRP];
   bool d_ok[GRP];
 #pragma unroll
   for (int i = 0; i < GRP; ++i) {
-    const int row = (wid * GRP + i) * 8 + r8;
-    const int chunk = cpos ^ ((row >> 1) & 7);
+    const int row = (wid * GRP + i) * RPI + r8;
+    const int chunk = cpos ^ swz(row);
     d_row[i] = row;
     d_ok[i] = chunk * 8 < p.head_dim;
     d_off[i] = (unsigned)((int64_t)row * p.k_row * 2 + chunk * 16);
@@ -494,8 +500,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
     for (int i = 0; i < GRP; ++i) {
       if (d_ok[i]) {
         const unsigned off = (kv0 + d_row[i] < p.nk) ? d_off[i] + adv : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(Ks + (wid * GRP + i) * 8 * ROW), 16, off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (__attribute__((address_space(3))) void*)(Vs + (wid * GRP + i) * 8 * ROW), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(Ks + (wid * GRP + i) * RPI * ROW), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (__attribute__((address_space(3))) void*)(Vs + (wid * GRP + i) * RPI * ROW), 16, off, 0, 0, 0);
       }
     }
   };
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         const int row = kt * 16 + l15;
-        const u32x4 kf = ld16(Ks + row * ROW + (((kc * 4 + g) ^ ((row >> 1) & 7)) << 3));
+        const u32x4 kf = ld16(Ks + row * ROW + (((kc * 4 + g) ^ swz(row)) << 3));
 #pragma unroll
         for (int t = 0; t < QT; ++t) sacc[t][kt] = Elem<DT>::mfma(kf, qf[t][kc], sacc[t][kt]);
       }
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         const int row = kt * 16 + l15;
-        const u32x2 kf = *reinterpret_cast<const u32x2*>(Ks + row * ROW + (((DK32 * 4 + (g >> 1)) ^ ((row >> 1) & 7)) << 3) + (g & 1) * 4);
+        const u32x2 kf = *reinterpret_cast<const u32x2*>(Ks + row * ROW + (((DK32 * 4 + (g >> 1)) ^ swz(row)) << 3) + (g & 1) * 4);
 #pragma unroll
         for (int t = 0; t < QT; ++t) sacc[t][kt] = Elem<DT>::mfma16(kf, qf16[t], sacc[t][kt]);
       }
@@ -647,9 +653,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
         const int col = dt * 16 + 4 * (l15 & 3);
         const int r0 = c * 32 + 4 * g + (l15 >> 2), r1 = r0 + 16;
         const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) v4s*)(Vs + r0 * ROW + (((col >> 3) ^ ((r0 >> 1) & 7)) << 3) + (col & 7)));
+            (__attribute__((address_space(3))) v4s*)(Vs + r0 * ROW + (((col >> 3) ^ swz(r0)) << 3) + (col & 7)));
         const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) v4s*)(Vs + r1 * ROW + (((col >> 3) ^ ((r1 >> 1) & 7)) << 3) + (col & 7)));
+            (__attribute__((address_space(3))) v4s*)(Vs + r1 * ROW + (((col >> 3) ^ swz(r1)) << 3) + (col & 7)));
         const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
         const u32x4 vf = {lo2[0], lo2[1], hi2[0], hi2[1]};
 #pragma unroll
@@ -970,6 +976,15 @@ int launch_attn(const AttnKParams& p, hipStream_t st) {
   const int d = p.head_dim;
   if (attn_short_eligible(p)) {
     launch_attn_short<DT>(p, st);
+    return CA_OK;
+  }
+  static const int dma80_env = CA_KNOB("CA_ATTN_DMA80", 1);
+  if (dma80_env && d > 64 && d <= 80 && d % 16 == 0 && !p.causal && !p.key_mask && p.nk >= 256 && p.k_row % 8 == 0 &&
+      ((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2 < (int64_t)0xFFFFFF00ll) {
+    // d = 80 on the LDS-DMA kernel: 32 + 32 + 16 deep, 256-byte LDS rows (no free pad column: neither the ones column nor the folded maximum)
+    AttnKParams q = p;
+    q.qblocks = ceil_div_i(p.nq, 128);
+    hipLaunchKernelGGL((k_attn_dma<DT, 2, 5, 2, 4, 64, false, false, true>), dim3((unsigned)(q.qblocks * p.batches * p.heads)), dim3(256), 0, st, q);
     return CA_OK;
   }
   if (d <= 32) launch_attn_d<DT, 1, 2>(p, st);

@@ -310,7 +310,9 @@ def _sdpa(q, k_, v):  # [B, H, N, d] fp32
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("images,tokens,heads,d", [(2, 256, 8, 40), (2, 100, 8, 80), (1, 64, 8, 160), (3, 16, 4, 8),
                                                   (2, 4, 8, 16), (2, 1, 8, 32), (1, 1024, 8, 40), (1, 300, 2, 64),
-                                                  (1, 200, 2, 128), (2, 144, 8, 160)])
+                                                  (1, 200, 2, 128), (2, 144, 8, 160),
+                                                  # (d = 80, >= 256 keys: the LDS-DMA kernel with 256-byte rows, ragged and whole tiles)
+                                                  (1, 1024, 8, 80), (2, 300, 8, 80), (2, 256, 4, 80)])
 def test_attention_spatial(images, tokens, heads, d, dtype):
     k = _k()
     c = heads * d
