@@ -82,8 +82,9 @@ struct Elem<CA_F16> {
 
 // Two fp32 values -> one register of two 16-bit elements, round to nearest even.  (Round 4: written as a vector conversion hipcc
 // emits ONE v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 instead of the 3-4 instructions below -- measured on the whole step: no gain
-// (61.04 / 60.74 vs 60.89 / 60.36 ms), and the bf16 d = 40 attention kernel then returns wrong values (rel 0.1: the packed
-// conversion reads MFMA results the hazard recogniser does not protect).  Kept scalar.)
+// (61.04 / 60.74 vs 60.89 / 60.36 ms), and the bf16 d = 40 attention kernel then returns wrong values (rel 0.1; cause not
+// isolated -- hipcc's wait-state accounting around MFMA results is not airtight on this target, see k_attn_short in ca_attention.hip).
+// Kept scalar.)
 template <int DT>
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   return (unsigned)Elem<DT>::from_f(lo) | ((unsigned)Elem<DT>::from_f(hi) << 16);
