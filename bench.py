@@ -84,6 +84,10 @@ def parse():
                          "(tests/test_graph_gpu.py), ~1 ms instead of ~50 ms of host time per step, so the loop stays "
                          "GPU-bound when N ranks share one host; falls back to eager if the capture fails")
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)  # (old spelling of the default)
+    ap.add_argument("--steps-in-flight", type=int, default=None,
+                    help="ControlAnimationPipeline.steps_in_flight: how many denoise steps the host may enqueue ahead of the device "
+                         "before it sleeps on a blocking HIP event (default: the pipeline's own, 2; 0 = unpaced, the round-4 behaviour "
+                         "-- the host then spins in the runtime for most of every step)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="multi-rank plumbing rehearsal WITHOUT the hot path (runs on a CPU box over gloo): rendezvous, "
                          "weight-arena broadcast, barriers, max-over-ranks timing, rank-0 JSON with `dry_run: true` and "
@@ -558,6 +562,19 @@ def matrix_rate_vs_operand_data(dtype):
         del a, w
     return res
 
+def thread_cpu_seconds() -> dict:
+    """user + system CPU seconds of every thread of this process (/proc/self/task/*/stat, fields 14 and 15)."""
+    out, tick = {}, os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            with open(f"/proc/self/task/{tid}/stat") as fh:
+                rest = fh.read().rsplit(")", 1)[1].split()
+            out[tid] = (int(rest[11]) + int(rest[12])) / tick
+    except OSError:
+        pass
+    return out
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -636,6 +653,8 @@ def main():
     pipe.use_hip_graph = not args.no_graph
     pipe.overlap_controlnet = not args.no_overlap
     pipe.fuse_controlnet_adds = not args.no_fuse_adds
+    if args.steps_in_flight is not None:
+        pipe.steps_in_flight = args.steps_in_flight
     lat0 = latents * float(getattr(sched, "init_noise_sigma", 1.0))
     gen = torch.Generator(device="cpu").manual_seed(4321)
     state = {"latents": lat0}
@@ -690,9 +709,12 @@ def main():
     replays_before = state.get("replays", 0)
     t0 = time.perf_counter()
     c0 = time.process_time()
+    th0 = thread_cpu_seconds()
     run_k_steps(args.steps, record_events=True)
-    host_enqueue = time.perf_counter() - t0  # the calls have returned, the GPU is still working
+    host_enqueue = time.perf_counter() - t0  # the calls have returned (a paced pipeline has also slept until its window was done)
     host_cpu = time.process_time() - c0      # CPU time of the process (all threads) over the same calls
+    th1 = thread_cpu_seconds()
+    host_threads = sorted(((th1[k] - th0.get(k, 0.0), k) for k in th1), reverse=True)[:3]
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -769,6 +791,8 @@ def main():
         # an idle queue, ~12 ms behind a running step), so this is mostly waiting, not work
         "host_cpu_ms_per_step": round(1e3 * host_cpu / args.steps, 3),
         "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
+        "host_cpu_ms_per_step_by_thread": [round(1e3 * d / args.steps, 3) for d, _ in host_threads],  # the three busiest threads
+        "steps_in_flight": int(pipe.steps_in_flight),
         "step_algorithmic_tflop": round(step_tflop, 2),
         # utilisation of the dense MFMA peak by the work that was EXECUTED (the shared CFG prefix runs once: see below);
         # `step_mfma_frac_algorithmic` divides the reference's count (both halves) by the same time and overstates it

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CA_HIP_LIB") or os.path.join(_HERE, "csrc", "libcontr
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class CAHipUnavailable(RuntimeError):
@@ -158,6 +158,7 @@ SYMBOLS = {
     "ca_groupnorm": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),
     "ca_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "ca_attention": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    "ca_attention_plan_name": (C.c_int, [C.POINTER(AttnArgs), C.c_char_p, C.c_int32]),
     "ca_add_bcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "ca_repeat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "ca_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -194,6 +194,8 @@ class ControlAnimatePipeline:
         torch.manual_seed(seed)                                   # global RNG: in-tree LCM noise (:129)
         self.generator = torch.Generator(device="cpu").manual_seed(seed)  # initial latents (:130)
         pos, neg = self._prompt_embeds()
+        if image_prompt_embeds is not None:  # a fixed IP-Adapter image prompt instead of the previous window's first frame
+            extra = dict(extra, image_prompt_embeds=image_prompt_embeds, uncond_image_prompt_embeds=uncond_image_prompt_embeds)
         out = self.pipeline(
             prompt_embeds=pos, negative_prompt_embeds=neg, input_frames=input_frames,
             num_inference_steps=int(_get(config, "steps")), strength=float(_get(config, "strength", 1.0)),

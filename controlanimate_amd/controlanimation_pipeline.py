@@ -50,6 +50,13 @@ class ControlAnimationPipeline:
         # instead of ~50 ms of host time per step: with 8 ranks on one host the loop stays GPU-bound.  A failed capture is
         # logged and the window runs eagerly (`graph_fallback_reason`).
         self.use_hip_graph = True
+        # How far the host may run ahead of the device, in denoise steps.  An unpaced loop enqueues faster than the device
+        # drains (a replay is ~3 us of host time per kernel against ~75 us of device time), fills the hardware queue and then
+        # SPINS inside the runtime for the rest of every step: two cores per rank for nothing (round 4: 122 ms of CPU per
+        # 59 ms step).  With a bound the loop sleeps on a `blocking=True` HIP event (interrupt wait, no CPU) until the
+        # step `steps_in_flight` steps back has finished; 2 keeps one whole step queued behind the running one, so the device
+        # never waits for the host.  0 = unpaced (the old behaviour).  The end of a window is awaited the same way.
+        self.steps_in_flight = 2
         self.fuse_controlnet_adds = True  # (False: separate ca_add_bcast passes, as round 2 -- A/B runs and the tests that compare the two)
         self._graph_state = None
         self._noise_state = None
@@ -222,6 +229,14 @@ class ControlAnimationPipeline:
             video = torch.stack(frames, dim=2)
         return (video / 2 + 0.5).clamp(0, 1).cpu().float().numpy()
 
+    def _pace_event(self, i: int):
+        """Blocking HIP events of the pacing ring (created once: an event per step would be 20 create / destroy pairs per window)."""
+        ring = self.__dict__.setdefault("_pace_ring", [])
+        n = max(1, int(self.steps_in_flight)) + 1
+        while len(ring) < n:
+            ring.append(torch.cuda.Event(blocking=True))
+        return ring[i % n]
+
     # ---- what a captured hipGraph of the step reads besides its own pool ---------------------------------------------
     @staticmethod
     def _model_cache_owners(unet, nets):
@@ -286,7 +301,18 @@ class ControlAnimationPipeline:
 
         # IP-Adapter tokens (:698-710)
         if self.ip_adapter is not None:
-            if last_output_frames is not None or kwargs.get("clip_image_embeds") is not None:
+            fixed_tok, fixed_untok = kwargs.get("image_prompt_embeds"), kwargs.get("uncond_image_prompt_embeds")
+            if fixed_tok is not None:
+                # a FIXED image prompt (the tokens `get_image_embeds_4controlanimate` returns, computed once by the caller): the
+                # window does not look at the previous window's output, so windows stay independent problems and can be
+                # sharded (vid2vid.run_video_sharded).  The reference's animate() has these two parameters
+                # (modules/controlanimate_pipeline.py:124-127) and never forwards them; here they are live.
+                if fixed_untok is None:
+                    raise ValueError("image_prompt_embeds needs uncond_image_prompt_embeds (both outputs of get_image_embeds_4controlanimate)")
+                self.ip_adapter.set_scale(ipa_scale)
+                prompt_embeds = torch.cat([prompt_embeds, fixed_tok.to(device).float().view(1, -1, prompt_embeds.shape[-1])], dim=1)
+                negative_prompt_embeds = torch.cat([negative_prompt_embeds, fixed_untok.to(device).float().view(1, -1, prompt_embeds.shape[-1])], dim=1)
+            elif last_output_frames is not None or kwargs.get("clip_image_embeds") is not None:
                 img_tok, uncond_tok = self.ip_adapter.get_image_embeds_4controlanimate(
                     pil_image=None if last_output_frames is None else last_output_frames[0], scale=ipa_scale,
                     clip_image_embeds=kwargs.get("clip_image_embeds"))
@@ -433,9 +459,13 @@ class ControlAnimationPipeline:
                 st["done"].record()
             return st["dev"]
 
+        pace_n = int(self.steps_in_flight) if device.type == "cuda" else 0
+        pace = []  # blocking events, one per step in flight (oldest first)
         for i, t in enumerate(timesteps):
             idx = first + i
             in_scale = sched.input_scale(idx)
+            if pace_n > 0 and len(pace) >= pace_n:
+                pace.pop(0).synchronize()  # sleeps: hipEventBlockingSync
             if use_graph:
                 K.latents_to_nhwc(latents, cpad, rep, in_scale, unet.act_dtype, out=gs["x"])   # [(rep f), h, w, 8]
                 gs["t"].fill_(float(t))
@@ -479,8 +509,14 @@ class ControlAnimationPipeline:
                                                     want_denoised=use_lcm)
             if use_lcm:
                 denoised = den
+            if pace_n > 0:
+                ev = self._pace_event(i)
+                ev.record()
+                pace.append(ev)
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, latents)
+        if pace:  # the caller's next device read (decode, .cpu()) would spin on the stream: sleep until the window is done
+            pace[-1].synchronize()
         final = denoised if use_lcm else latents
         if output_type == "latent" or self.vae is None:
             video = final

@@ -708,13 +708,58 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   }
 }
 
+// Which kernel a launch takes.  ONE function decides (ca_attention_plan_name reports it, the launchers switch on it), so a
+// parity test can assert that the headline shapes really ran on the kernels the design names.
+enum AttnPlan { AP_SHORT, AP_DMA80, AP_DMA40_K16, AP_DMA_FOLD, AP_DMA_SR, AP_DMA, AP_TINY16, AP_TINY32, AP_GENERIC };
+
+static bool attn_short_eligible(const AttnKParams& p);
+
+static AttnPlan attn_plan(const AttnKParams& p) {
+  const int d = p.head_dim;
+  if (attn_short_eligible(p)) return AP_SHORT;
+  const bool dma_ok = !p.causal && !p.key_mask && p.nk >= 256 && p.k_row % 8 == 0 &&
+                      ((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2 < (int64_t)0xFFFFFF00ll;
+  static const int dma80_env = CA_KNOB("CA_ATTN_DMA80", 1);
+  // d = 80 on the LDS-DMA kernel: 32 + 32 + 16 deep, 256-byte LDS rows (no free pad column: neither the ones column nor the folded maximum)
+  if (dma80_env && d > 64 && d <= 80 && d % 16 == 0 && dma_ok) return AP_DMA80;
+  if (p.nq <= 16 && p.nk <= 32 && !p.causal && !p.key_mask) return AP_TINY16;
+  if (p.nq <= 32 && p.nk <= 32 && !p.causal && !p.key_mask) return AP_TINY32;
+  static const int dma_env = CA_KNOB("CA_ATTN_DMA", 1);
+  if (d <= 64 && dma_env && dma_ok) {
+    const int dv16 = d <= 32 ? 2 : d <= 48 ? 3 : 4, dk32 = d <= 32 ? 1 : 2;
+    // the ones column needs a free, 16-byte aligned pad chunk inside the last 16-wide dv tile
+    static const int sr_env = CA_KNOB("CA_ATTN_SR", 1);
+    const bool sr = sr_env && d % 8 == 0 && d / 16 == dv16 - 1;
+    static const int fold_env = CA_KNOB("CA_ATTN_FOLD", 1);
+    const bool fold = sr && fold_env && d + 8 <= dk32 * 32;
+    static const int k16_env = CA_KNOB("CA_ATTN_K16", 1);
+    if (fold && k16_env && dk32 == 2 && dv16 == 3 && d >= 32 && d <= 44) return AP_DMA40_K16;  // head_dim 40: 32 + 16 instead of 64 deep
+    return fold ? AP_DMA_FOLD : sr ? AP_DMA_SR : AP_DMA;
+  }
+  return AP_GENERIC;
+}
+
+static const char* attn_plan_label(AttnPlan pl) {
+  switch (pl) {
+    case AP_SHORT: return "attn_short";
+    case AP_DMA80: return "attn_dma80";
+    case AP_DMA40_K16: return "attn_dma40";
+    case AP_DMA_FOLD: return "attn_dma_fold";
+    case AP_DMA_SR: return "attn_dma_sr";
+    case AP_DMA: return "attn_dma";
+    case AP_TINY16: return "attn_tiny16";
+    case AP_TINY32: return "attn_tiny32";
+    default: return "attn_generic";
+  }
+}
+
 template <int DT, int DK32, int DV16>
-void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
+void launch_attn_d(const AttnKParams& p0, AttnPlan plan, hipStream_t st) {
   AttnKParams p = p0;
-  if (p.nq <= 16 && p.nk <= 32 && !p.causal && !p.key_mask) {
+  if (plan == AP_TINY16) {
     p.qblocks = 1;
     hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 1, 1, 32, false>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
-  } else if (p.nq <= 32 && p.nk <= 32 && !p.causal && !p.key_mask) {
+  } else if (plan == AP_TINY32) {
     p.qblocks = 1;
     hipLaunchKernelGGL((k_attn<DT, DK32, DV16, 2, 1, 32, false>), dim3((unsigned)(p.batches * p.heads)), dim3(64), 0, st, p);
   } else {
@@ -722,23 +767,14 @@ void launch_attn_d(const AttnKParams& p0, hipStream_t st) {
     static const int pf_env = CA_KNOB("CA_ATTN_PF", 1);  // tuning knob
     p.qblocks = ceil_div_i(p.nq, 128);
     const dim3 grid((unsigned)(p.qblocks * p.batches * p.heads));
-    static const int dma_env = CA_KNOB("CA_ATTN_DMA", 1);
-    if (DK32 <= 2 && dma_env && !p.causal && !p.key_mask && p.nk >= 256 && p.k_row % 8 == 0 &&
-        ((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2 < (int64_t)0xFFFFFF00ll) {
-      // the ones column needs a free, 16-byte aligned pad chunk inside the last 16-wide dv tile
-      static const int sr_env = CA_KNOB("CA_ATTN_SR", 1);
-      const bool sr = sr_env && p.head_dim % 8 == 0 && p.head_dim / 16 == DV16 - 1;
-      static const int fold_env = CA_KNOB("CA_ATTN_FOLD", 1);
-      const bool fold = sr && fold_env && p.head_dim + 8 <= DK32 * 32;
-      static const int k16_env = CA_KNOB("CA_ATTN_K16", 1);
-      if (fold && k16_env && DK32 == 2 && DV16 == 3 && p.head_dim >= 32 && p.head_dim <= 44) {  // head_dim 40: 32 + 16 instead of 64 deep
-        hipLaunchKernelGGL((k_attn_dma<DT, 1, 3, 2, 4, 64, true, true, true>), grid, dim3(256), 0, st, p);
+    if constexpr (DK32 <= 2) {
+      if (plan == AP_DMA40_K16) {
+        if constexpr (DK32 == 2 && DV16 == 3) hipLaunchKernelGGL((k_attn_dma<DT, 1, 3, 2, 4, 64, true, true, true>), grid, dim3(256), 0, st, p);
         return;
       }
-      if (fold) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, true>), grid, dim3(256), 0, st, p);
-      else if (sr) hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, false>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, false, false>), grid, dim3(256), 0, st, p);
-      return;
+      if (plan == AP_DMA_FOLD) { hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, true>), grid, dim3(256), 0, st, p); return; }
+      if (plan == AP_DMA_SR) { hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, true, false>), grid, dim3(256), 0, st, p); return; }
+      if (plan == AP_DMA) { hipLaunchKernelGGL((k_attn_dma<DT, DK32, DV16, 2, 4, 64, false, false>), grid, dim3(256), 0, st, p); return; }
     }
     static const int var_env = CA_KNOB("CA_ATTN_VAR", 0);  // experiments (d <= 48 only)
     if (DK32 == 2 && DV16 == 3 && var_env == 1) {  // KB = 128
@@ -974,31 +1010,50 @@ static void launch_attn_short(const AttnKParams& p, hipStream_t st) {
 template <int DT>
 int launch_attn(const AttnKParams& p, hipStream_t st) {
   const int d = p.head_dim;
-  if (attn_short_eligible(p)) {
+  const AttnPlan plan = attn_plan(p);
+  if (plan == AP_SHORT) {
     launch_attn_short<DT>(p, st);
     return CA_OK;
   }
-  static const int dma80_env = CA_KNOB("CA_ATTN_DMA80", 1);
-  if (dma80_env && d > 64 && d <= 80 && d % 16 == 0 && !p.causal && !p.key_mask && p.nk >= 256 && p.k_row % 8 == 0 &&
-      ((int64_t)(p.nk - 1) * p.k_row + p.head_dim) * 2 < (int64_t)0xFFFFFF00ll) {
-    // d = 80 on the LDS-DMA kernel: 32 + 32 + 16 deep, 256-byte LDS rows (no free pad column: neither the ones column nor the folded maximum)
+  if (plan == AP_DMA80) {
     AttnKParams q = p;
     q.qblocks = ceil_div_i(p.nq, 128);
     hipLaunchKernelGGL((k_attn_dma<DT, 2, 5, 2, 4, 64, false, false, true>), dim3((unsigned)(q.qblocks * p.batches * p.heads)), dim3(256), 0, st, q);
     return CA_OK;
   }
-  if (d <= 32) launch_attn_d<DT, 1, 2>(p, st);
-  else if (d <= 48) launch_attn_d<DT, 2, 3>(p, st);
-  else if (d <= 64) launch_attn_d<DT, 2, 4>(p, st);
-  else if (d <= 80) launch_attn_d<DT, 3, 5>(p, st);
-  else if (d <= 128) launch_attn_d<DT, 4, 8>(p, st);
-  else launch_attn_d<DT, 5, 10>(p, st);
+  if (d <= 32) launch_attn_d<DT, 1, 2>(p, plan, st);
+  else if (d <= 48) launch_attn_d<DT, 2, 3>(p, plan, st);
+  else if (d <= 64) launch_attn_d<DT, 2, 4>(p, plan, st);
+  else if (d <= 80) launch_attn_d<DT, 3, 5>(p, plan, st);
+  else if (d <= 128) launch_attn_d<DT, 4, 8>(p, plan, st);
+  else launch_attn_d<DT, 5, 10>(p, plan, st);
   return CA_OK;
 }
 
 }  // namespace
 
+static int attn_params(const ca_attn_args* a, AttnKParams& p);
+
+extern "C" int ca_attention_plan_name(const ca_attn_args* a, char* buf, int32_t len) {
+  CA_REQUIRE(buf != nullptr && len > 0, "ca_attention_plan_name: no buffer");
+  AttnKParams p{};
+  const int rc = attn_params(a, p);
+  if (rc != CA_OK) return rc;
+  snprintf(buf, (size_t)len, "%s", attn_plan_label(attn_plan(p)));
+  return CA_OK;
+}
+
 extern "C" int ca_attention(const ca_attn_args* a, void* stream) {
+  AttnKParams p{};
+  const int rc = attn_params(a, p);
+  if (rc != CA_OK) return rc;
+  if (a->dtype == CA_BF16) launch_attn<CA_BF16>(p, (hipStream_t)stream);
+  else launch_attn<CA_F16>(p, (hipStream_t)stream);
+  CA_CHECK_LAUNCH("ca_attention");
+  return CA_OK;
+}
+
+static int attn_params(const ca_attn_args* a, AttnKParams& p) {
   CA_REQUIRE(a != nullptr, "ca_attention: null args");
   CA_REQUIRE(a->q && a->k && a->v && a->o, "ca_attention: null operand");
   CA_REQUIRE(a->head_dim > 0 && a->head_dim % 8 == 0 && a->head_dim <= 160, "ca_attention: head_dim=%d must be a multiple of 8 and <= 160", a->head_dim);
@@ -1009,7 +1064,6 @@ extern "C" int ca_attention(const ca_attn_args* a, void* stream) {
              "ca_attention: batch strides misaligned");
   CA_REQUIRE(a->dtype == CA_BF16 || a->dtype == CA_F16, "ca_attention: dtype %d", a->dtype);
   CA_REQUIRE((int64_t)a->batches * a->heads * ceil_div_i(a->nq, 128) < (1ll << 31), "ca_attention: grid too large");
-  AttnKParams p{};
   p.q = (const u16*)a->q;
   p.k = (const u16*)a->k;
   p.v = (const u16*)a->v;
@@ -1039,8 +1093,5 @@ extern "C" int ca_attention(const ca_attn_args* a, void* stream) {
     const int dvp = d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : d <= 80 ? 80 : d <= 128 ? 128 : 160;
     p.sum_row = (d < dvp && d % 4 == 0) ? 1 : 0;
   }
-  if (a->dtype == CA_BF16) launch_attn<CA_BF16>(p, (hipStream_t)stream);
-  else launch_attn<CA_F16>(p, (hipStream_t)stream);
-  CA_CHECK_LAUNCH("ca_attention");
   return CA_OK;
 }

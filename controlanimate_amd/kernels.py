@@ -387,6 +387,7 @@ def attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Te
                     kv_mod=kv_mod if kv_mod > 0 else batches, batches=batches, heads=heads, head_dim=head_dim, nq=nq, nk=nk, scale=scale, out_scale=out_scale,
                     accumulate=int(accumulate), dtype=dt_code(q.dtype), causal=int(causal),
                     key_mask=_p(key_mask), key_mask_stride=key_mask.stride(0) if key_mask is not None else 0)
+    _record_plan(lib().ca_attention_plan_name, args)
     check(lib().ca_attention(C.byref(args), _stream()), "ca_attention")
 
 

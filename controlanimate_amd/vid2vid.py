@@ -336,7 +336,9 @@ def blend_windows(windows: Sequence[Sequence], overlap_length: int,
 
 
 def run_video_sharded(config, frames: Sequence, components: Optional[dict] = None,
-                      match_colors_fn: Optional[Callable[[Sequence, object], List]] = match_colors, device=None):
+                      match_colors_fn: Optional[Callable[[Sequence, object], List]] = match_colors, device=None,
+                      image_prompt_embeds=None, uncond_image_prompt_embeds=None, ip_reference_image=None,
+                      single_rank_group: bool = False):
     """The window loop of scripts/vid2vid.py:168-268 over the GPUs of one node: one process per GPU (torchrun or any launcher
     that sets RANK / LOCAL_RANK / WORLD_SIZE), every rank calls this with the same `config` and the same input `frames`.
 
@@ -353,7 +355,20 @@ def run_video_sharded(config, frames: Sequence, components: Optional[dict] = Non
     test_facade_gpu.py::test_sharded_video_equals_sequential) -- only when nothing flows from window k to window k + 1 before
     the blend: `overlap_strength >= 1` (no latent initialisation from the previous output, :566-604), `loop_back_frames` off
     (:197-199), no IP-Adapter conditioning on the previous window's frame (:698-710).  Any other configuration is a chain by
-    construction and is refused here; run it with `run_windows` on one GPU.  (A sampler that draws its step noise
+    construction and is refused here; run it with `run_windows` on one GPU.
+
+    IP-Adapter (BASELINE config 4): the windows ARE independent when the image prompt is FIXED for the whole video instead of
+    following the previous window.  Three sources, first match wins:
+      * `image_prompt_embeds` / `uncond_image_prompt_embeds` -- the two parameters of the reference's animate()
+        (modules/controlanimate_pipeline.py:124-127): the [1, 4, 768] token tensors of `get_image_embeds_4controlanimate`;
+      * `ip_reference_image` -- a PIL image; rank 0 runs it through the CLIP vision encoder + ImageProjModel;
+      * `do_initial_generation` in the config -- the reference's "initial round to acquire a baseline for the IP Adapter"
+        (scripts/vid2vid.py:199-212): rank 0 generates window 0 once without an image prompt and takes its FIRST output frame
+        as the baseline image (`last_output_frame = frames[0]`, :203).
+    Whatever the source, the tokens are computed on rank 0 and broadcast (two 12 KB tensors), every window of every rank gets
+    them through animate(image_prompt_embeds=...), and the result equals `run_windows` driven with the same fixed tokens
+    (tests/test_facade_gpu.py::test_sharded_ip_adapter_video_equals_sequential).  With `use_ipadapter` and none of the three
+    the windows form a chain and the call is refused as before.  (A sampler that draws its step noise
     from the SAME generator as the VAE's latent sampling -- diffusers' ancestral / LCM samplers -- sees a different generator
     state in the two modes, because the sequential loop also encodes the previous window's frames: statistically the same
     video, not the same bits.  Deterministic samplers and the native LCM sampler, whose noise comes from the global RNG that
@@ -367,9 +382,13 @@ def run_video_sharded(config, frames: Sequence, components: Optional[dict] = Non
                          "latents and the windows form a chain (use run_windows on one GPU)")
     if bool(_get(config, "loop_back_frames", False)) and overlap > 0:
         raise ValueError("window sharding needs loop_back_frames off: looped-back frames are the previous window's OUTPUT")
-    if bool(_get(config, "use_ipadapter", 0)):
-        raise ValueError("window sharding is not available with the IP-Adapter: it conditions a window on the previous window's frame")
-    rank, world, local_rank = WS.init_distributed()
+    use_ip = bool(_get(config, "use_ipadapter", 0))
+    initial_round = use_ip and bool(_get(config, "do_initial_generation", False))
+    if use_ip and image_prompt_embeds is None and ip_reference_image is None and not initial_round:
+        raise ValueError("window sharding with the IP-Adapter needs a FIXED image prompt (image_prompt_embeds + uncond_image_prompt_embeds, "
+                         "ip_reference_image, or do_initial_generation in the config): conditioned on the previous window's frame the "
+                         "windows form a chain (use run_windows on one GPU)")
+    rank, world, local_rank = WS.init_distributed(single_rank_group=single_rank_group)
     if device is None:
         device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     if torch.device(device).type == "cuda":
@@ -387,9 +406,31 @@ def run_video_sharded(config, frames: Sequence, components: Optional[dict] = Non
                  strength=float(_get(config, "overlap_strength", 1.0)) if later else float(_get(config, "strength", 1.0)))
         return c
 
+    ip_kw = {}
+    if use_ip:
+        ip = pipe.pipeline.ip_adapter
+        tok_shape = (1, ip.num_tokens, int(pipe.pipeline.unet.config.cross_attention_dim))
+        both = torch.zeros((2,) + tok_shape, device=device, dtype=torch.float32)
+        if rank == 0:
+            if image_prompt_embeds is not None:
+                if uncond_image_prompt_embeds is None:
+                    raise ValueError("image_prompt_embeds needs uncond_image_prompt_embeds")
+                tok, untok = image_prompt_embeds, uncond_image_prompt_embeds
+            else:
+                image = ip_reference_image
+                if image is None:  # the reference's initial round (:199-203): window 0 without an image prompt, first frame = baseline
+                    s0, e0 = plan[0]
+                    image = pipe.animate(frames[s0:e0], None, cfg_of(0))[0]
+                tok, untok = ip.get_image_embeds_4controlanimate(pil_image=image, scale=float(_get(config, "ipa_scale", 0.4)))
+            both[0].copy_(tok.to(device).float().view(tok_shape))
+            both[1].copy_(untok.to(device).float().view(tok_shape))
+        WS.broadcast_tensor(both, src=0)
+        ip_kw = dict(image_prompt_embeds=both[0], uncond_image_prompt_embeds=both[1])
+        run_video_sharded.last_image_prompt = both.cpu()
+
     def run_window(k: int) -> torch.Tensor:
         s, e = plan[k]
-        out = pipe.animate(frames[s:e], None, cfg_of(k))
+        out = pipe.animate(frames[s:e], None, cfg_of(k), **ip_kw)
         return torch.from_numpy(np.stack([_to_np(f) for f in out]))  # [n, H, W, 3] uint8
 
     windows = WS.run_sharded(len(plan), run_window, rank, world)

@@ -20,22 +20,51 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init_distributed(backend: Optional[str] = None, single_rank_group: bool = False) -> Tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; initialises the default group when
-    WORLD_SIZE > 1 ("nccl" = RCCL on ROCm when a GPU is present, "gloo" on CPU test runs)."""
+    WORLD_SIZE > 1 ("nccl" = RCCL on ROCm when a GPU is present, "gloo" on CPU test runs).
+
+    `single_rank_group=True` initialises it for WORLD_SIZE == 1 as well: the collectives of this module then really run
+    (RCCL communicator of one rank: init, device broadcast, object gather, barrier) instead of returning early -- the 1-GPU
+    proof that the `nccl` branch works (tests/test_window_shard_nccl_gpu.py).
+
+    Rendezvous: MASTER_ADDR defaults to 127.0.0.1 (one node).  MASTER_PORT has NO fixed default: a launcher (torchrun,
+    `bench.py --gpus N`) chooses it and hands the same value to every rank; a single-rank group picks a free port itself.  (A
+    hard-wired 29500 collides as soon as two jobs share a host.)"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         if backend is None:
             # CA_DIST_BACKEND=gloo: several ranks sharing ONE GPU (rehearsal of the multi-rank flow on a 1-GPU box)
             backend = os.environ.get("CA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise RuntimeError("init_distributed: WORLD_SIZE > 1 but MASTER_PORT is not set -- every rank must be given the same "
+                                   "port by its launcher (torchrun --master-port, bench.py --gpus N); there is no fixed default")
+            os.environ["MASTER_PORT"] = str(_free_port())
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+            torch.cuda.set_device(dev)
+            kw["device_id"] = dev  # binds the communicator to this GPU: barrier() needs no device_ids guess
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
+
+
+def _group_active() -> bool:
+    """True when collectives should run: an initialised default group (of any size, a single-rank group included)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def window_plan(num_frames: int, frame_count: int, overlap_length: int) -> List[Tuple[int, int]]:
@@ -64,7 +93,7 @@ def windows_for_rank(num_windows: int, rank: int, world: int) -> List[int]:
 def broadcast_weights(buffers: Sequence[torch.Tensor], src: int = 0) -> int:
     """Broadcasts the packed weight arenas (one contiguous uint8 tensor each) from `src`.
     Returns the number of bytes moved. No-op for a single process."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _group_active():
         return 0
     # every rank must hand over the same list -- a rank whose skeleton packs one tensor more, less or differently would
     # otherwise hang in a broadcast or run on garbage weights: compare (numel, dtype) manifests first, on ALL ranks, so that
@@ -87,7 +116,7 @@ def broadcast_weights(buffers: Sequence[torch.Tensor], src: int = 0) -> int:
 
 def gather_window_results(local: List[Tuple[int, torch.Tensor]], num_windows: int, dst: int = 0) -> Optional[List[torch.Tensor]]:
     """Collects (window index, result) pairs on `dst`, returned in window order (None elsewhere)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _group_active():
         out: List[Optional[torch.Tensor]] = [None] * num_windows
         for i, t in local:
             out[i] = t
@@ -103,6 +132,18 @@ def gather_window_results(local: List[Tuple[int, torch.Tensor]], num_windows: in
         for i, t in part:
             out[i] = t
     return out  # type: ignore[return-value]
+
+
+def broadcast_tensor(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """In-place broadcast of one (device or host) tensor from `src`: the fixed IP-Adapter image prompt of a sharded video."""
+    if _group_active():
+        dist.broadcast(t, src=src)
+    return t
+
+
+def barrier() -> None:
+    if _group_active():
+        dist.barrier()
 
 
 def blend_overlap(prev_tail: torch.Tensor, cur_head: torch.Tensor) -> torch.Tensor:

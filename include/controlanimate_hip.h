@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 11
+#define CA_ABI_VERSION 12
 
 /* element types */
 #define CA_BF16 0
@@ -395,6 +395,11 @@ typedef struct ca_attn_args {
   int64_t key_mask_stride;
 } ca_attn_args;
 int ca_attention(const ca_attn_args* args, void* stream);
+/* ABI v12: the label of the kernel ca_attention runs for these arguments ("attn_dma40" the LDS-DMA kernel at head_dim 40,
+ * "attn_dma80", "attn_dma_fold" / "attn_dma_sr" / "attn_dma", "attn_short" the register-resident text cross-attention,
+ * "attn_tiny16" / "attn_tiny32" the one-wave temporal forms, "attn_generic").  No launch, no device access: the parity tests
+ * assert with it that the headline shapes ran on the kernels DESIGN.md names (tests/test_fullsize_gpu.py, test_dispatch_plan.py). */
+int ca_attention_plan_name(const ca_attn_args* args, char* buf, int32_t len);
 
 /* ------------------------------------------------------------------------------------
  * Small elementwise kernels of the loop.

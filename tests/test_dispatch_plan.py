@@ -259,3 +259,50 @@ def test_fused_text_cross_attention_only_takes_what_it_implements(capi):
         assert lib.ca_xattn_pack_w(args[0], args[1], args[2], args[3], None) < 0
     assert lib.ca_xattn_pack_kv(FAKE, 640, 2, 77, 0, 64, 0.158, capi.CA_F16, FAKE, None) < 0   # 64 keys: not this kernel's
     assert lib.ca_xattn_pack_kv(FAKE, 640, 2, 77, 4, 77, 0.158, capi.CA_F16, FAKE, None) < 0   # rows beyond the batch
+
+
+def attn_label(capi, *, images, nq, nk, heads, d, kind="self", accumulate=0, causal=0, mask=False):
+    """Strides as kernels.attention_spatial / attention_cross / attention_temporal hand them over."""
+    c = heads * d
+    if kind == "self":          # q | k | v rows of width 3C
+        a = capi.AttnArgs(q=FAKE, k=FAKE, v=FAKE, o=FAKE, q_outer=nq * 3 * c, q_row=3 * c, o_outer=nq * c, o_row=c, k_outer=nq * 3 * c, k_row=3 * c,
+                          inner_count=1, kv_inner_count=1, kv_div=1, kv_mod=images)
+    elif kind == "cross":       # q rows of width C, k | v rows of width 2C, one K/V per 16 frames
+        a = capi.AttnArgs(q=FAKE, k=FAKE, v=FAKE, o=FAKE, q_outer=nq * c, q_row=c, o_outer=nq * c, o_row=c, k_outer=nk * 2 * c, k_row=2 * c,
+                          inner_count=1, kv_inner_count=1, kv_div=16, kv_mod=2)
+    else:                       # temporal: images = b * tokens sequences of `nq` frames, rows tokens * 3C apart
+        tokens = images // 2
+        a = capi.AttnArgs(q=FAKE, k=FAKE, v=FAKE, o=FAKE, q_outer=nq * tokens * 3 * c, q_inner=3 * c, q_row=tokens * 3 * c, o_outer=nq * tokens * c,
+                          o_inner=c, o_row=tokens * c, k_outer=nq * tokens * 3 * c, k_inner=3 * c, k_row=tokens * 3 * c, inner_count=tokens,
+                          kv_inner_count=tokens, kv_div=1, kv_mod=images)
+    a.batches, a.heads, a.head_dim, a.nq, a.nk, a.scale, a.out_scale = images, heads, d, nq, nk, d ** -0.5, 1.0
+    a.accumulate, a.causal, a.dtype = accumulate, causal, capi.CA_F16
+    if mask:
+        a.key_mask, a.key_mask_stride = FAKE, nk
+    buf = C.create_string_buffer(64)
+    rc = capi.lib().ca_attention_plan_name(C.byref(a), buf, 64)
+    assert rc == 0, capi.lib().ca_last_error()
+    return buf.value.decode()
+
+
+ATTN_TABLE = [
+    # the attentions of a config-2 step that are still separate launches (ABI v12: ca_attention_plan_name)
+    (dict(images=32, nq=4096, nk=4096, heads=8, d=40), "attn_dma40"),       # spatial self-attention, 64x64 latents
+    (dict(images=32, nq=1024, nk=1024, heads=8, d=80), "attn_dma80"),       # 32x32 latents
+    (dict(images=32, nq=256, nk=256, heads=8, d=160), "attn_generic"),      # 16x16 latents
+    (dict(images=32, nq=64, nk=64, heads=8, d=160), "attn_generic"),        # mid block
+    (dict(images=32, nq=4096, nk=77, heads=8, d=40, kind="cross"), "attn_short"),
+    (dict(images=32, nq=1024, nk=77, heads=8, d=80, kind="cross"), "attn_short"),
+    (dict(images=32, nq=256, nk=77, heads=8, d=160, kind="cross"), "attn_generic"),
+    (dict(images=32, nq=4096, nk=4, heads=8, d=40, kind="cross", accumulate=1), "attn_generic"),   # IP-Adapter pass (config 4)
+    (dict(images=2 * 1024, nq=16, nk=16, heads=8, d=80, kind="temporal"), "attn_tiny16"),   # motion modules below the 64x64 level
+    (dict(images=2 * 256, nq=32, nk=32, heads=8, d=160, kind="temporal"), "attn_tiny32"),   # config 5: 32 frames
+    (dict(images=2, nq=77, nk=77, heads=12, d=64, causal=1), "attn_generic"),              # CLIP text encoder
+    (dict(images=1, nq=257, nk=257, heads=16, d=80), "attn_dma80"),                       # CLIP ViT-H vision tower
+    (dict(images=2, nq=512, nk=512, heads=8, d=40, mask=True), "attn_generic"),            # a key mask keeps the generic kernel
+]
+
+
+@pytest.mark.parametrize("kw,label", ATTN_TABLE, ids=[f"{l}-{k['nq']}x{k['nk']}-d{k['d']}" for k, l in ATTN_TABLE])
+def test_attention_dispatch(capi, kw, label):
+    assert attn_label(capi, **kw) == label

@@ -124,3 +124,105 @@ def test_sharded_video_equals_sequential(tmp_path):
     sharded = np.load(out_path)
     assert sharded.shape == seq.shape
     assert np.array_equal(sharded, seq), f"{int((sharded != seq).sum())} bytes differ"
+
+
+# ---- BASELINE config 4's shape of problem: IP-Adapter + window sharding (fixed image prompt) ----------------------------------
+def _img_enc(pil):
+    """Stand-in for the CLIP vision tower (PIL -> [1, 1024] image embedding), deterministic in the pixels."""
+    a = np.asarray(pil.convert("RGB").resize((16, 16)), dtype=np.float32).reshape(-1) / 255.0 - 0.5
+    return torch.from_numpy(np.concatenate([a, np.zeros(1024 - a.size, np.float32)])[None])
+
+
+_IP_CFG = dict(use_lcm=0, use_ipadapter=1, ipa_scale=0.6, controlnets=["lllyasviel/control_v11p_sd15_canny"], cond_scale=[0.8],
+               scheduler="DDIMScheduler", prompt="a red fox running", n_prompt="blurry", seed=7, width=64, height=64, steps=3, strength=1.0,
+               overlap_strength=1.0, guidance_scale=1.3, frame_count=8, overlap_length=4, overlaps=0, epoch=0, guess_mode=0, use_img2img=True,
+               loop_back_frames=False)
+
+
+def _ip_pipe(perturb=False):
+    from controlanimate_amd.controlanimate_pipeline import ControlAnimatePipeline
+    comps = dict(_components(), image_encoder=_img_enc)
+    torch.manual_seed(2024)  # the IP processors' to_k_ip / to_v_ip and the ImageProjModel are initialised from the global RNG
+    return ControlAnimatePipeline(_IP_CFG, comps, device=DEV)
+
+
+def _sharded_ip_worker(rank, world, port, seed_frames, ref_image, out_path):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      CA_DIST_BACKEND="gloo")
+    from controlanimate_amd import vid2vid
+    rng = np.random.default_rng(seed_frames)
+    frames = [Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)) for _ in range(20)]
+    comps = dict(_components(), image_encoder=_img_enc)
+    torch.manual_seed(2024 if rank == 0 else 77)  # rank 1: other IP / projection weights, replaced by the broadcast
+    if rank != 0:
+        for m in (comps["unet"], comps["controlnets"][0]):
+            for p in m.parameters():
+                p.data.normal_(std=0.02)
+    out = vid2vid.run_video_sharded(_IP_CFG, frames, components=comps, device="cuda:0", ip_reference_image=ref_image)
+    if rank == 0:
+        np.save(out_path, np.stack([np.asarray(f) for f in out]))
+        np.save(out_path + ".tok.npy", vid2vid.run_video_sharded.last_image_prompt.numpy())
+    else:
+        assert out is None
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_ip_adapter_video_equals_sequential(tmp_path):
+    """use_ipadapter + window sharding: with a FIXED image prompt (here `ip_reference_image`, embedded on rank 0 and broadcast) the
+    windows are independent, and the two-rank result equals the sequential window loop driven with the same tokens through the
+    reference's animate(image_prompt_embeds=, uncond_image_prompt_embeds=) parameters -- byte for byte."""
+    import socket
+    import torch.multiprocessing as mp
+    from controlanimate_amd import vid2vid
+    rng = np.random.default_rng(321)
+    frames = [Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)) for _ in range(20)]
+    ref_image = Image.fromarray(np.random.default_rng(5).integers(0, 255, (64, 64, 3), dtype=np.uint8))
+    pipe = _ip_pipe()
+    tok, untok = pipe.pipeline.ip_adapter.get_image_embeds_4controlanimate(pil_image=ref_image, scale=_IP_CFG["ipa_scale"])
+    assert tok.shape == (1, 4, 768) and untok.shape == (1, 4, 768) and float((tok - untok).abs().max()) > 0
+    wc = vid2vid.WindowConfig(frame_count=8, overlap_length=4, strength=1.0, overlap_strength=1.0, loop_back_frames=False)
+
+    def animate(batch, last, c, **kw):
+        return pipe.animate(batch, last, dict(_IP_CFG, frame_count=c.frame_count, strength=c.strength, overlaps=c.overlaps, epoch=c.epoch), **kw)
+
+    seq = np.stack([np.asarray(f) for win in vid2vid.run_windows(
+        frames, lambda b, l, c: animate(b, l, c, image_prompt_embeds=tok, uncond_image_prompt_embeds=untok), wc) for f in win])
+    # the image prompt is live: without it (zero tokens on both halves, reference :707-710) the video differs
+    wc0 = vid2vid.WindowConfig(frame_count=8, overlap_length=4, strength=1.0, overlap_strength=1.0, loop_back_frames=False)
+    plain = np.stack([np.asarray(f) for f in animate(frames[:8], None, wc0)])
+    first_fixed = np.stack([np.asarray(f) for f in animate(frames[:8], None, wc0, image_prompt_embeds=tok, uncond_image_prompt_embeds=untok)])
+    assert not np.array_equal(plain, first_fixed)
+    # refused without a fixed prompt: the windows would form a chain
+    with pytest.raises(ValueError, match="FIXED image prompt"):
+        vid2vid.run_video_sharded(_IP_CFG, frames, components=None, device=DEV)
+    del pipe
+    torch.cuda.empty_cache()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "sharded_ip.npy")
+    mp.spawn(_sharded_ip_worker, args=(2, port, 321, ref_image, out_path), nprocs=2, join=True)
+    sharded = np.load(out_path)
+    assert np.allclose(np.load(out_path + ".tok.npy"), torch.stack([tok, untok]).cpu().numpy())
+    assert sharded.shape == seq.shape == (20, 64, 64, 3)
+    assert np.array_equal(sharded, seq), f"{int((sharded != seq).sum())} bytes differ"
+
+
+def test_sharded_ip_adapter_initial_generation_baseline():
+    """`do_initial_generation` (scripts/vid2vid.py:199-203): rank 0 generates window 0 without an image prompt and its first output
+    frame becomes the baseline image of the whole video (single process: no group, the same code path minus the broadcast)."""
+    from controlanimate_amd import vid2vid
+    rng = np.random.default_rng(11)
+    frames = [Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)) for _ in range(12)]
+    cfg = dict(_IP_CFG, do_initial_generation=True)
+    comps = dict(_components(), image_encoder=_img_enc)
+    torch.manual_seed(2024)
+    out = vid2vid.run_video_sharded(cfg, frames, components=comps, device=DEV)
+    assert len(out) == 12
+    got = vid2vid.run_video_sharded.last_image_prompt
+    pipe = _ip_pipe()
+    base = pipe.animate(frames[:8], None, dict(cfg, frame_count=8))[0]
+    tok, untok = pipe.pipeline.ip_adapter.get_image_embeds_4controlanimate(pil_image=base, scale=cfg["ipa_scale"])
+    assert torch.allclose(got, torch.stack([tok, untok]).cpu().float(), atol=1e-6)

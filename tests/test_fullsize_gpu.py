@@ -89,6 +89,38 @@ def test_config2_full_size_eps_vs_oracle():
     print("kernel labels of the step:", {k: labels.count(k) for k in kinds})
     # the step really ran the headline instantiations, not the small-shape ones
     assert any(k.startswith("wres") or k.startswith("ps") for k in kinds) and any("320" in k for k in kinds), kinds
+    # ---- the PRODUCT's step, as ControlAnimationPipeline.model_eps runs it and bench.py times it: channels-last latents in,
+    # both CFG halves declared identical (shared prefix), the ControlNet stack on the second stream with its 13 residual adds
+    # inside the zero convolutions' epilogues, device-side timestep, the whole thing captured ONCE as a hipGraph and replayed.
+    # Held to the same fp32 oracle, directly -- not through a chain of bit-equality tests -- and every one-launch /
+    # headline kernel must have run: a `_supported` gate that says no at a config-2 shape FAILS here instead of falling back.
+    lat_d, prompt_d = lat.to(DEV), prompt.to(DEV)
+    x = K.latents_to_nhwc(lat_d, unet.conv_in.cin_pad, 2, 1.0, torch.float16)
+    t_dev = torch.full((1,), float(t), device=DEV)
+
+    def product_step():
+        dn = cn.residuals_nhwc_async(x, t_dev, prompt_d, False, cfg_identical_halves=True, fuse_images=x.shape[0])
+        return unet.forward_nhwc(x, 2, f, t_dev, prompt_d, dn, None, cfg_identical_halves=True)
+
+    K._plan_sink = plabels = []
+    try:
+        eps_eager = product_step().clone()   # (also warms the per-window caches and the allocator before the capture)
+        torch.cuda.synchronize()
+    finally:
+        K._plan_sink = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eps_static = product_step()
+    eps_static.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(eps_static, eps_eager), "hipGraph replay differs from the eager product step"
+    eps_product = K.nhwc_to_ncfhw_f32(eps_static, 2, 4, f).cpu()
+    pk = {k: plabels.count(k) for k in sorted(set(plabels))}
+    print("kernel labels of the PRODUCT step:", pk)
+    for need in ("ar128x64", "ff_fused", "tattn_fused", "xattn_fused", "pq256x320", "attn_dma40", "attn_dma80", "attn_short", "wres160", "ps128x320"):
+        assert any(k.startswith(need) for k in pk), f"the product step at config-2 size never ran `{need}`: {pk}"
+    del graph, eps_static, eps_eager
     del unet, net, cn, down, mid, out
     gc.collect()
     torch.cuda.empty_cache()
@@ -104,6 +136,9 @@ def test_config2_full_size_eps_vs_oracle():
     for i, e in enumerate(errs[:-1]):
         assert e < 1e-2, f"ControlNet residual {i}: rel_l2 {e:.3e}"
     assert errs[-1] < 1e-2, f"eps rel_l2 {errs[-1]:.3e}"   # BASELINE north_star tolerance
+    e_prod = rel(eps_product, ref)
+    print("config-2 full size, PRODUCT path (forward_nhwc + shared CFG prefix + fused adds + second stream + hipGraph): eps rel_l2 = %.3e" % e_prod)
+    assert e_prod < 1e-2, f"product-path eps rel_l2 {e_prod:.3e}"
 
 
 def test_config2_size_properties():
