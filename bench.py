@@ -586,6 +586,11 @@ def main():
         return plumbing_only(args)
     from controlanimate_amd import kernels as K
     from controlanimate_amd import window_shard as WS
+    from controlanimate_amd.context import dispatch
+    from tools import ab_switches
+    switched_off = ab_switches.apply_from_env()  # (A/B runs only: the product has every form on and reads no environment)
+    if switched_off:
+        print(f"[bench] A/B run, switched off: {sorted(switched_off)}", file=sys.stderr)
     from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
     from controlanimate_amd.schedulers import get_scheduler
     from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
@@ -758,7 +763,7 @@ def main():
     cn_tflop = wl["cn_tflop"] * scale
     step_tflop = wl["unet_tflop"] * scale + len(nets) * cn_tflop
     shared_tflop = 0.0
-    if rep == 2 and os.environ.get("CA_CFG_SHARED", "1") != "0":
+    if rep == 2 and dispatch.cfg_shared:
         rows_half, n_tok = f * (wl["height"] // 8) * (wl["width"] // 8), (wl["height"] // 8) * (wl["width"] // 8)
         one = (2 * 2.0 * rows_half * 320 * 2880 + 2.0 * rows_half * 320 * 1600 + 4.0 * n_tok * n_tok * 320 * f) * 1e-12
         shared_tflop = one * (1 + (0 if cn_single else len(nets)))  # UNet + every ControlNet that sees both halves
@@ -800,7 +805,7 @@ def main():
         "step_mfma_frac_algorithmic": round(step_tflop / sec_per_step / PEAK_MFMA_TFLOPS, 4),
         # classifier-free guidance repeats ONE latent tensor for both batch halves: up to the first cross-attention (conv_in,
         # first resnet, first transformer's GroupNorm / proj_in / 4096-token self-attention) the halves are the same
-        # computation, which runs once (bit-identical results: tests/test_workload_configs_gpu.py; CA_CFG_SHARED=0 disables).  The
+        # computation, which runs once (bit-identical results: tests/test_workload_configs_gpu.py; CA_CFG_SHARED=0 disables it for an A/B run).  The
         # algorithmic count above is the reference's, which computes both halves; this is what was executed.
         "cfg_shared_prefix": bool(shared_tflop > 0),
         "step_executed_tflop": round(step_tflop - shared_tflop, 2),

@@ -26,3 +26,20 @@ class ExecCtx:
 
     def rows_per_emb_group(self, h: int, w: int) -> int:
         return self.images // self.emb_groups * h * w
+
+
+class Dispatch:
+    """Which of the one-launch / fused forms the host side hands to the library.  All on: that is the product, and no
+    product module reads the environment to change it.  A/B timing runs flip these attributes from OUTSIDE the package
+    (tools/ab_switches.py maps the CA_* variables of earlier rounds onto them for `bench.py`; tests set them directly)."""
+    gemm_ar = True        # fragment-ordered W handed to ca_gemm (activation-resident K = 320 kernel)
+    ff_fused = True       # ca_ff_fused for the C = 320 feed-forward
+    tattn_fused = True    # ca_tattn_fused for the 64x64-latent motion modules
+    xattn_fused = True    # ca_xattn_fused for the 64x64-latent text cross-attention
+    ln_row_sums = True    # LayerNorm statistics from the producing GEMM's epilogue
+    repeat_kernel = True  # ca_repeat instead of torch.cat for the CFG-shared prefix
+    ln_fold = True        # LayerNorm folded into the projection it feeds
+    cfg_shared = True     # the prompt-independent prefix of the two CFG halves runs once
+
+
+dispatch = Dispatch()

@@ -229,6 +229,12 @@ class ControlAnimationPipeline:
             video = torch.stack(frames, dim=2)
         return (video / 2 + 0.5).clamp(0, 1).cpu().float().numpy()
 
+    def release_graph(self) -> None:
+        """Drops the captured hipGraph with its private memory pool and every object its signature keeps alive (models, weight
+        arenas, per-window caches, control images).  Called by __call__ when a call runs without replay; call it yourself after
+        swapping or releasing models.  The next graph-mode call captures again."""
+        self._graph_state = None
+
     def _pace_event(self, i: int):
         """Blocking HIP events of the pacing ring (created once: an event per step would be 20 create / destroy pairs per window)."""
         ring = self.__dict__.setdefault("_pace_ring", [])
@@ -374,6 +380,10 @@ class ControlAnimationPipeline:
         self.graph_replays = 0
         self.graph_fallback_reason = None
         gs = None
+        if not use_graph and self._graph_state is not None:
+            # a call that does not replay (use_hip_graph off, a one-step call): let go of the captured graph and of what it pins
+            # (the models, their weight arenas and caches, the control images) instead of holding GBs through the pipeline object
+            self.release_graph()
         if use_graph:
             hh, ww = latents.shape[3], latents.shape[4]
             nets = list(getattr(cn, "controlnets", [])) if cn is not None else []

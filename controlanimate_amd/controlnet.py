@@ -178,8 +178,8 @@ class ControlNetModel(HipModelMixin, nn.Module):
         # CFG-doubled input (the caller repeated one latent tensor, `cfg_identical_halves`) with CFG-doubled hints: the two
         # halves are identical up to the first cross-attention -- see UNet3DConditionModel.forward_nhwc
         first = self.down_blocks[0]
-        from .unet import _CFG_SHARED_ON
-        shared = (cfg_identical_halves and _CFG_SHARED_ON and images % 2 == 0 and bool(getattr(self, "_hint_doubled", False)) and
+        from .context import dispatch
+        shared = (cfg_identical_halves and dispatch.cfg_shared and images % 2 == 0 and bool(getattr(self, "_hint_doubled", False)) and
                   getattr(first, "has_cross_attention", False) and (not torch.is_tensor(timestep) or timestep.numel() == 1))
         if shared:
             half = images // 2

@@ -17,6 +17,8 @@
 #define CA_ATTN_SETPRIO 0  // measured: no gain on this kernel (1.67 vs 1.61 ms)
 #endif
 
+int ar_cu_count();
+
 namespace {
 
 template <bool B>
@@ -984,14 +986,7 @@ static bool attn_short_eligible(const AttnKParams& p) {
 
 template <int DT>
 static void launch_attn_short(const AttnKParams& p, hipStream_t st) {
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  static int cu_cached = 0;
-  if (!cu_cached) {
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    cu_cached = cus;
-  }
-  cus = cu_cached;
+  const int cus = ar_cu_count();  // (per device, ca_gemm_ar.hip)
   const int qtiles = ceil_div_i(p.nq, 16);
   // query tiles per item: whole items per block, about one item per CU or more
   const int qc = (int64_t)p.batches * ceil_div_i(qtiles, 16) >= cus ? 16 : 8;

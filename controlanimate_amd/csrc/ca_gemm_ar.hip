@@ -1,5 +1,21 @@
 // Activation-resident K = 320 GEMM (ca_gemm_ar.h): separate translation unit (compile time).
 #include "ca_gemm_core.h"
+#include <atomic>
+
+// CU count of the CURRENT device, cached per device id (a process may drive devices with different CU counts -- partition
+// modes -- and first calls may race: the slots are written once each with the same value, atomically).
+int ar_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
 
 namespace {
 using namespace ca_gemm_detail;
@@ -7,17 +23,6 @@ using namespace ca_gemm_detail;
 #include "ca_ff_fused.h"
 #include "ca_tattn_fused.h"
 #include "ca_xattn_fused.h"
-
-int ar_cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
 
 template <int DT>
 int launch_ar(const GemmKParams& p, hipStream_t st) {
@@ -65,7 +70,10 @@ extern "C" int ca_ff_fused_supported(const ca_ff_args* a) {
   if (a->c != 320 || a->inner != 1280 || a->m < 16384) return 0;
   if (a->dtype != CA_BF16 && a->dtype != CA_F16) return 0;
   if (a->lda % 8 || a->ldc % 8 || (a->residual && a->ld_res % 8)) return 0;
+  if (a->lda < 320 || a->ldc < 320 || (a->residual && a->ld_res < 320)) return 0;  // rows must not overlap
   if ((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->w1_frag | (uintptr_t)a->w2_frag | (uintptr_t)a->residual) & 15) != 0) return 0;
+  // fp32 operands: the kernel reads ln_stats as float2 and the bias / column-sum tables as float4
+  if (((uintptr_t)a->ln_stats & 7) != 0 || (((uintptr_t)a->bias1 | (uintptr_t)a->colsum1 | (uintptr_t)a->bias2) & 15) != 0) return 0;
   const int64_t lim = 0x7FFFFF00ll;
   if (((int64_t)(a->m - 1) * a->lda + 320) * 2 >= lim || ((int64_t)(a->m - 1) * a->ldc + 320) * 2 >= lim) return 0;
   if (a->residual && ((int64_t)(a->m - 1) * a->ld_res + 320) * 2 >= lim) return 0;

@@ -6,12 +6,12 @@ torch is used only for device memory and streams; every arithmetic op below is a
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Optional
 
 import torch
 
 from . import _capi
+from .context import dispatch
 from ._capi import (AttnArgs, ConvArgs, FfArgs, TattnArgs, XattnArgs, GemmArgs, GroupNormArgs, LayerNormArgs, CA_ACT_NONE,
                     CA_ACT_SILU, CA_BF16, CA_F16, check, lib)
 
@@ -84,7 +84,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
                     post_scale=post_scale, act=act, geglu=int(geglu), out_f32=int(out_f32),
                     dtype=dt_code(a.dtype))
     frag = getattr(w, "_frag", None)  # (tensor, geglu flag it was packed for): attach_w_frag
-    if frag is not None and frag[1] == bool(geglu) and _AR_ON:
+    if frag is not None and frag[1] == bool(geglu) and dispatch.gemm_ar:
         args.w_frag = _p(frag[0])
     if ln is not None:
         st, cs = ln
@@ -118,7 +118,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
             args.ln_stats = _p(st)
     if hasattr(out, "_row_sums"):  # a caller-supplied `out` reused from an earlier call: its sums describe the old contents
         del out._row_sums
-    if row_sums and _ROW_SUMS_ON and not geglu and not out_f32:
+    if row_sums and dispatch.ln_row_sums and not geglu and not out_f32:
         parts = int(lib().ca_gemm_row_sums_parts(C.byref(args)))
         if parts > 0:  # the epilogue leaves (sum, sum of squares) per row and 320-column tile: the next LayerNorm's statistics
             rs = torch.empty((m, parts, 2), device=a.device, dtype=torch.float32)
@@ -131,9 +131,6 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     _record_plan(lib().ca_gemm_plan_name, args)
     check(lib().ca_gemm(C.byref(args), _stream()), "ca_gemm")
     return out
-
-
-_AR_ON = os.environ.get("CA_GEMM_AR_PY", "1") != "0"  # (0: never hand the fragment-ordered weights over -- A/B runs)
 
 
 def attach_w_frag(w: torch.Tensor, geglu: bool = False) -> torch.Tensor:
@@ -149,15 +146,12 @@ def attach_w_frag(w: torch.Tensor, geglu: bool = False) -> torch.Tensor:
     return w
 
 
-_FF_FUSED_ON = os.environ.get("CA_FF_FUSED", "1") != "0"  # (0: the feed-forward always as two GEMMs -- A/B runs)
-
-
 def ff_fused(x: torch.Tensor, w1_frag: torch.Tensor, bias1: torch.Tensor, colsum1: torch.Tensor, w2_frag: torch.Tensor,
              bias2: Optional[torch.Tensor], ln_eps: float, residual: Optional[torch.Tensor] = None,
              ln_stats: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """y = GEGLU(LN(x) W1^T + b1) W2^T + b2 + residual in one launch (ca_ff_fused, ABI v9: the 64x64-latent level's feed-forward,
     C = 320) -- or None where the library does not take the arguments (the caller then runs the two GEMMs)."""
-    if not _FF_FUSED_ON:
+    if not dispatch.ff_fused:
         return None
     _req_cuda(x, w1_frag, bias1, colsum1, w2_frag, bias2, residual, ln_stats)
     if x.dim() != 2 or x.stride(1) != 1 or (residual is not None and (residual.shape != x.shape or residual.stride(1) != 1 or residual.dtype != x.dtype)):
@@ -176,15 +170,12 @@ def ff_fused(x: torch.Tensor, w1_frag: torch.Tensor, bias1: torch.Tensor, colsum
     return y
 
 
-_TATTN_FUSED_ON = os.environ.get("CA_TATTN_FUSED", "1") != "0"  # (0: temporal attention always as q|k|v GEMM + attention -- A/B runs)
-
-
 def tattn_fused(x: torch.Tensor, w_frag: torch.Tensor, gamma: torch.Tensor, bias_pe: torch.Tensor, b: int, frames: int, tokens: int,
                 heads: int, ln_eps: float, scale: float) -> Optional[torch.Tensor]:
     """o = softmax(q k^T scale) v over the frame axis with q|k|v = (LayerNorm(x) + pe[frame]) Wqkv^T in one launch (ca_tattn_fused,
     ABI v10: the motion modules of the 64x64-latent level) -- or None where the library does not take the arguments (the caller
     then runs the folded q|k|v GEMM and attention_temporal).  x rows in (b f n) order; bias_pe [>= frames, C] fp32."""
-    if not _TATTN_FUSED_ON:
+    if not dispatch.tattn_fused:
         return None
     _req_cuda(x, w_frag, gamma, bias_pe)
     if x.dim() != 2 or x.stride(1) != 1 or x.shape[0] != b * frames * tokens or bias_pe.shape[0] < frames or bias_pe.stride(1) != 1:
@@ -202,14 +193,11 @@ def tattn_fused(x: torch.Tensor, w_frag: torch.Tensor, gamma: torch.Tensor, bias
     return o
 
 
-_XATTN_FUSED_ON = os.environ.get("CA_XATTN_FUSED", "1") != "0"  # (0: text cross-attention always as q GEMM + attention -- A/B runs)
-
-
 def xattn_pack_kv(kv: torch.Tensor, kv_batches: int, rows_per_batch: int, nk: int, scale: float, row_offset: int = 0,
                   out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """The K | V rows of `kv` [kv_batches * rows_per_batch, 2 * 320] as the MFMA fragments ca_xattn_fused reads (ca_xattn_pack_kv,
     ABI v11; once per window and layer) -- or None for shapes the fused kernel does not take."""
-    if not _XATTN_FUSED_ON or kv.dim() != 2 or kv.shape[1] != 640 or kv.stride(1) != 1 or not (64 < nk <= 80) or kv.dtype not in (torch.float16, torch.bfloat16):
+    if not dispatch.xattn_fused or kv.dim() != 2 or kv.shape[1] != 640 or kv.stride(1) != 1 or not (64 < nk <= 80) or kv.dtype not in (torch.float16, torch.bfloat16):
         return None
     _req_cuda(kv)
     dst = out if out is not None else torch.empty((kv_batches, 8, _capi.XATTN_KV_FRAG_ELEMS), device=kv.device, dtype=kv.dtype)
@@ -223,16 +211,18 @@ def xattn_fused(x: torch.Tensor, wq_frag: torch.Tensor, bias: Optional[torch.Ten
                 frames_per_kv: int, kv_mod: int, nk: int, ln_eps: float) -> Optional[torch.Tensor]:
     """o = softmax(q K^T scale) V with q = LayerNorm(x) Wq^T + bias in one launch (ca_xattn_fused, ABI v11: the text cross-attention of
     the 64x64-latent level) -- or None where the library does not take the arguments (the caller then runs the folded q GEMM and
-    attention_cross).  kv_frag from xattn_pack_kv; image z uses its text batch (z // frames_per_kv) % kv_mod."""
-    if not _XATTN_FUSED_ON or kv_frag is None:
+    attention_cross).  kv_frag from xattn_pack_kv; image z uses its text batch (z // frames_per_kv) % kv_mod, kv_mod = 0 meaning `images`
+    exactly as attention_cross does (the library refuses a launch that would index past the packed text batches)."""
+    if not dispatch.xattn_fused or kv_frag is None:
         return None
     _req_cuda(x, wq_frag, bias, kv_frag)
     if x.dim() != 2 or x.stride(1) != 1 or x.shape[0] != images * tokens:
         return None
+    assert kv_frag.dtype == x.dtype and wq_frag.dtype == x.dtype, "ca_xattn_fused: x, the packed Wq and the packed K/V must share one dtype"
     c = x.shape[1]
     o = torch.empty((x.shape[0], c), device=x.device, dtype=x.dtype)
     args = XattnArgs(x=_p(x), wq_frag=_p(wq_frag), bias=_p(bias), kv_frag=_p(kv_frag), o=_p(o), lda=x.stride(0), ldo=o.stride(0), m=x.shape[0],
-                     tokens=tokens, frames_per_kv=frames_per_kv, kv_mod=kv_mod if kv_mod > 0 else kv_frag.shape[0], kv_batches=kv_frag.shape[0],
+                     tokens=tokens, frames_per_kv=frames_per_kv, kv_mod=kv_mod if kv_mod > 0 else images, kv_batches=kv_frag.shape[0],
                      nk=nk, heads=8, c=c, ln_eps=float(ln_eps), dtype=dt_code(x.dtype))
     if not lib().ca_xattn_fused_supported(C.byref(args)):
         return None
@@ -240,9 +230,6 @@ def xattn_fused(x: torch.Tensor, wq_frag: torch.Tensor, bias: Optional[torch.Ten
         _plan_sink.append("xattn_fused128")
     check(lib().ca_xattn_fused(C.byref(args), _stream()), "ca_xattn_fused")
     return o
-
-
-_ROW_SUMS_ON = os.environ.get("CA_LN_ROWSUMS", "1") != "0"  # (0: always the separate statistics pass -- A/B runs)
 
 
 def row_sums_of(t: torch.Tensor):
@@ -449,12 +436,9 @@ def add_bcast(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = No
     return out
 
 
-_REPEAT_ON = os.environ.get("CA_REPEAT_KERNEL", "1") != "0"
-
-
 def repeat_batch(x: torch.Tensor, times: int = 2) -> torch.Tensor:
-    """torch.cat([x] * times) along dim 0 with one read of x (ca_repeat, ABI v8; CA_REPEAT_KERNEL=0: torch.cat, for A/B runs)."""
-    if not _REPEAT_ON:
+    """torch.cat([x] * times) along dim 0 with one read of x (ca_repeat, ABI v8; context.dispatch.repeat_kernel = False: torch.cat, for A/B runs)."""
+    if not dispatch.repeat_kernel:
         return torch.cat([x] * times)
     _req_cuda(x)
     if not x.is_contiguous():

@@ -250,9 +250,9 @@ def pack_concat_bias(arena: WeightArena, mods: Sequence[nn.Module]) -> Packed:
 
 
 def ln_fold_enabled() -> bool:
-    """CA_LN_FOLD=0 keeps LayerNorm as its own kernel (A/B measurements)."""
-    import os
-    return os.environ.get("CA_LN_FOLD", "1") != "0"
+    """context.dispatch.ln_fold = False keeps LayerNorm as its own kernel (A/B measurements, set from outside the package)."""
+    from .context import dispatch
+    return bool(dispatch.ln_fold)
 
 
 class LnFold:

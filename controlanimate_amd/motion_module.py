@@ -66,7 +66,9 @@ class VersatileAttention(Attention):
         # operands of the one-launch form (K.tattn_fused: C = 320, 8 heads, 16 frames): the UNFOLDED q|k|v weights in fragment
         # order, the LayerNorm weight and (LayerNorm bias + positional encoding) per frame -- the kernel normalises its x tile in place
         self.tfrag = self.tgamma = self.tbias_pe = None
-        if self.fold is not None and pe is not None and (self.heads, self.inner_dim, self.query_dim) == (8, 320, 320):
+        # (the kernel has no projection-bias operand: with attention_bias=True -- no reference config -- the two-launch path runs)
+        no_bias = all(getattr(m, "bias", None) is None for m in (self.to_q, self.to_k, self.to_v))
+        if self.fold is not None and pe is not None and no_bias and (self.heads, self.inner_dim, self.query_dim) == (8, 320, 320):
             from .layers import _f32, frag_order_tattn
             self.tfrag = arena.add((368640,), dtype, lambda: frag_order_tattn(torch.cat([_f32(m.weight) for m in (self.to_q, self.to_k, self.to_v)], 0)))
             self.tgamma = arena.add((320,), torch.float32, lambda: _f32(fold_ln.weight))

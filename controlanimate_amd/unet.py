@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
-from .context import ExecCtx
+from .context import ExecCtx, dispatch
 from .layers import HipGroupNorm, HipLinear, WeightArena, pack_concat_bias, pack_concat_rows
 from .resnet import InflatedConv3d, InflatedGroupNorm, ResnetBlock3D
 from .unet_blocks import UNetMidBlock3DCrossAttn, get_down_block, get_up_block
@@ -64,9 +64,6 @@ class TimestepEmbedding(nn.Module):
         self.linear_2.pack(arena, dtype)
         if self.cond_proj is not None:
             self.cond_proj.pack(arena, dtype)
-
-
-_CFG_SHARED_ON = os.environ.get("CA_CFG_SHARED", "1") != "0"  # (0: both CFG halves all the way -- A/B runs)
 
 
 class HipModelMixin:
@@ -385,7 +382,7 @@ class UNet3DConditionModel(HipModelMixin, nn.Module):
         cfg_identical_halves: the caller built `x` by repeating ONE latent tensor for the two classifier-free-guidance
         halves (`latents_to_nhwc(..., rep=2)`, reference :797) and passes one timestep for both: everything up to the first
         cross-attention -- conv_in, the first resnet, the first transformer's GroupNorm / proj_in / self-attention (the
-        4096-token one) -- is then the same computation twice and runs once (`CA_CFG_SHARED=0` disables)."""
+        4096-token one) -- is then the same computation twice and runs once (`context.dispatch.cfg_shared = False` disables: A/B runs)."""
         device = x.device
         self._ensure_ready(device)
         _, h, w, _ = x.shape
@@ -398,7 +395,7 @@ class UNet3DConditionModel(HipModelMixin, nn.Module):
         ctx = ExecCtx(b=b, f=f, dtype=self.act_dtype, temb=temb, emb_groups=b, ehs=ehs, frames_per_kv=f,
                       gn_frames_per_stat=1 if self.config.use_inflated_groupnorm else f, cache=cache)
         first = self.down_blocks[0]
-        shared = (cfg_identical_halves and _CFG_SHARED_ON and b == 2 and getattr(first, "has_cross_attention", False) and
+        shared = (cfg_identical_halves and dispatch.cfg_shared and b == 2 and getattr(first, "has_cross_attention", False) and
                   (not torch.is_tensor(timestep) or timestep.numel() == 1) and (timestep_cond is None or timestep_cond.shape[0] == 1))
         if shared:
             half_ctx = dataclasses.replace(ctx, b=1, temb=temb[:1], emb_groups=1)

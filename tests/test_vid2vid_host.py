@@ -167,3 +167,49 @@ def test_ffmpeg_pipe_class_and_prefetch():
     import pytest
     with pytest.raises(ValueError, match="decoder died"):
         list(prefetch(boom()))
+
+
+# ---- pinned to the REFERENCE's own loop: tests/golden/vid2vid_loop.json was captured from scripts/vid2vid.py::vid2vid() run
+# behind stand-ins for ffmpeg / omegaconf / the pipeline (tests/golden/make_vid2vid_golden.py); the same fakes drive run_windows
+import json
+import os
+
+import pytest
+
+_GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vid2vid_loop.json")))
+
+
+def _gray64(v):
+    return Image.fromarray(np.full((64, 64, 3), int(v) % 256, np.uint8))
+
+
+@pytest.mark.parametrize("name", sorted(_GOLD))
+def test_run_windows_follows_the_reference_loop(name):
+    """Every animate() call (inputs, last_output_frames, strength, overlaps, overlap flag, epoch, L, frame_count), every colour-match
+    reference frame and every frame written to the encoder, in order, as scripts/vid2vid.py:168-268 produced them."""
+    from controlanimate_amd.vid2vid import WindowConfig, run_windows
+    g = _GOLD[name]
+    c, n = g["config"], g["n_input_frames"]
+    calls, refs = [], []
+
+    def animate(batch, last, cfg):
+        calls.append(dict(inputs=[val(f) for f in batch], last=None if last is None else [val(f) for f in last], strength=float(cfg.strength),
+                          overlaps=int(cfg.overlaps), overlap=bool(cfg.overlap), epoch=int(cfg.epoch), L=int(cfg.L), frame_count=int(cfg.frame_count)))
+        # (= make_vid2vid_golden.animate_value)
+        return [_gray64((val(f) + 10 * cfg.epoch + (5 if last is not None else 0)) % 256) for f in batch]
+
+    def match(frames, ref):
+        refs.append(val(ref))
+        return [_gray64((val(f) + val(ref) % 3) % 256) for f in frames]
+
+    # the reference's frame budget (:62-79): fps x min(input duration, end - start), input duration = frames / input fps (10)
+    def secs(t):
+        h, m, s = (int(x) for x in t.split(":"))
+        return 3600 * h + 60 * m + s
+    budget = c["fps"] * min(n / 10.0, secs(c["end_time"]) - secs(c["start_time"]))
+    wc = WindowConfig(frame_count=c["frame_count"], overlap_length=c["overlap_length"], strength=c["strength"], overlap_strength=c["overlap_strength"],
+                      loop_back_frames=bool(c["loop_back_frames"]), do_initial_generation=bool(c["do_initial_generation"]))
+    written = [val(f) for w in run_windows((_gray64(i) for i in range(n)), animate, wc, total_frames=budget, match_colors=match) for f in w]
+    assert calls == g["animate"]
+    assert refs == g["match_colors"]
+    assert written == g["written"]
