@@ -92,6 +92,8 @@ def parse():
                     help="multi-rank plumbing rehearsal WITHOUT the hot path (runs on a CPU box over gloo): rendezvous, "
                          "weight-arena broadcast, barriers, max-over-ranks timing, rank-0 JSON with `dry_run: true` and "
                          "`value: null`.  Never a measurement; used by tests/test_bench_launch.py")
+    ap.add_argument("--pace-wait", default=None, choices=["sleep", "event"],
+                    help="how the paced loop waits: hipEventQuery polls between naps (default) or a blocking hipEventSynchronize (A/B)")
     args = ap.parse_args()
     if args.steps <= 0:
         args.steps = int(CONFIGS[args.config]["steps"])
@@ -563,13 +565,14 @@ def matrix_rate_vs_operand_data(dtype):
     return res
 
 def thread_cpu_seconds() -> dict:
-    """user + system CPU seconds of every thread of this process (/proc/self/task/*/stat, fields 14 and 15)."""
+    """user + system CPU seconds of every thread of this process (/proc/self/task/*/stat, fields 14 and 15), keyed "tid:name"."""
     out, tick = {}, os.sysconf("SC_CLK_TCK")
     try:
         for tid in os.listdir("/proc/self/task"):
             with open(f"/proc/self/task/{tid}/stat") as fh:
-                rest = fh.read().rsplit(")", 1)[1].split()
-            out[tid] = (int(rest[11]) + int(rest[12])) / tick
+                head, rest = fh.read().rsplit(")", 1)
+            rest = rest.split()
+            out[f"{tid}:{head.split('(', 1)[1]}"] = (int(rest[11]) + int(rest[12])) / tick
     except OSError:
         pass
     return out
@@ -660,6 +663,8 @@ def main():
     pipe.fuse_controlnet_adds = not args.no_fuse_adds
     if args.steps_in_flight is not None:
         pipe.steps_in_flight = args.steps_in_flight
+    if args.pace_wait is not None:
+        pipe.pace_wait = args.pace_wait
     lat0 = latents * float(getattr(sched, "init_noise_sigma", 1.0))
     gen = torch.Generator(device="cpu").manual_seed(4321)
     state = {"latents": lat0}
@@ -796,8 +801,8 @@ def main():
         # an idle queue, ~12 ms behind a running step), so this is mostly waiting, not work
         "host_cpu_ms_per_step": round(1e3 * host_cpu / args.steps, 3),
         "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
-        "host_cpu_ms_per_step_by_thread": [round(1e3 * d / args.steps, 3) for d, _ in host_threads],  # the three busiest threads
-        "steps_in_flight": int(pipe.steps_in_flight),
+        "host_cpu_ms_per_step_by_thread": {k.split(":", 1)[1] + "#" + k.split(":", 1)[0]: round(1e3 * d / args.steps, 3) for d, k in host_threads},  # the three busiest
+        "steps_in_flight": int(pipe.steps_in_flight), "pace_wait": str(pipe.pace_wait),
         "step_algorithmic_tflop": round(step_tflop, 2),
         # utilisation of the dense MFMA peak by the work that was EXECUTED (the shared CFG prefix runs once: see below);
         # `step_mfma_frac_algorithmic` divides the reference's count (both halves) by the same time and overstates it

@@ -1,0 +1,1 @@
+"""MI355X-native denoising loop of intellerce/controlanimate."""

@@ -7,7 +7,7 @@ travels to the GPU box with the repo snapshot.
 
 `--experiments` builds a SECOND library, `csrc/libcontrolanimate_hip_exp.so`, with -DCA_EXPERIMENTS: the same ABI plus
 the tuning environment variables (CA_KNOB in ca_common.h) and the kernels that never became defaults
-(ca_gemm_pp.h, ca_gemm_pp3.h).  It is loaded through CA_HIP_LIB for same-box A/B timing and is never the product path.
+(csrc/experiments/ca_gemm_pp.h, ca_gemm_pp3.h).  It is loaded through CA_HIP_LIB for same-box A/B timing and is never the product path.
 """
 from __future__ import annotations
 
@@ -19,7 +19,8 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcontrolanimate_hip.so")
 SOURCES = ["ca_gemm.hip", "ca_gemm_pp.hip", "ca_gemm_ar.hip", "ca_norm.hip", "ca_attention.hip", "ca_elementwise.hip"]
-HEADERS = ["ca_common.h", "ca_gemm_core.h", "ca_gemm_pp.h", "ca_gemm_pp2.h", "ca_gemm_pp3.h", "ca_gemm_wres.h", "ca_gemm_ps.h", "ca_gemm_pq.h", "ca_gemm_ar.h", "ca_ff_fused.h", "ca_tattn_fused.h", "ca_xattn_fused.h", "ca_gemm_seq.h", os.path.join("..", "..", "include", "controlanimate_hip.h")]
+EXPERIMENT_HEADERS = [os.path.join("experiments", "ca_gemm_pp.h"), os.path.join("experiments", "ca_gemm_pp3.h")]  # -DCA_EXPERIMENTS builds only
+HEADERS = ["ca_common.h", "ca_gemm_core.h", "ca_gemm_pp2.h", "ca_gemm_wres.h", "ca_gemm_ps.h", "ca_gemm_pq.h", "ca_gemm_ar.h", "ca_ff_fused.h", "ca_attn_out.h", "ca_tattn_fused.h", "ca_xattn_fused.h", "ca_gemm_seq.h", os.path.join("..", "..", "include", "controlanimate_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          # keep MFMA accumulators in the (unified) VGPR file: without it hipcc parks them in AGPRs and the
          # attention kernel spends ~200 v_accvgpr_read/write per K/V tile on the softmax rescale
@@ -55,7 +56,7 @@ LIB_STAMPS = os.path.join(CSRC, "libcontrolanimate_hip_stamps.so")  # --experime
 
 def build(force: bool = False, verbose: bool = True, experiments: bool = False, stamps: bool = False) -> str:
     hipcc = _hipcc()
-    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS + (EXPERIMENT_HEADERS if experiments else [])]
     jobs = []
     objs = []
     objdir = os.path.join(CSRC, "build_stamps" if stamps else "build_exp") if experiments else CSRC

@@ -56,9 +56,11 @@ class TattnArgs(C.Structure):
         ("lda", C.c_int64), ("ldo", C.c_int64), ("ld_bias_pe", C.c_int64),
         ("batch", C.c_int32), ("frames", C.c_int32), ("tokens", C.c_int32), ("heads", C.c_int32), ("c", C.c_int32),
         ("ln_eps", C.c_float), ("scale", C.c_float), ("dtype", C.c_int32),
+        ("w_out_frag", C.c_void_p), ("bias_out", C.c_void_p), ("residual", C.c_void_p), ("ld_res", C.c_int64),  # ABI v12
     ]
 
 
+ATTN_WOUT_FRAG_ELEMS = 102400  # CA_ATTN_WOUT_FRAG_ELEMS
 TATTN_W_FRAG_ELEMS = 368640  # CA_TATTN_W_FRAG_ELEMS
 
 
@@ -69,6 +71,7 @@ class XattnArgs(C.Structure):
         ("m", C.c_int32), ("tokens", C.c_int32), ("frames_per_kv", C.c_int32), ("kv_mod", C.c_int32), ("kv_batches", C.c_int32),
         ("nk", C.c_int32), ("heads", C.c_int32), ("c", C.c_int32),
         ("ln_eps", C.c_float), ("dtype", C.c_int32),
+        ("w_out_frag", C.c_void_p), ("bias_out", C.c_void_p), ("residual", C.c_void_p), ("ld_res", C.c_int64),  # ABI v12
     ]
 
 
@@ -138,6 +141,7 @@ SYMBOLS = {
     "ca_tattn_fused": (C.c_int, [C.POINTER(TattnArgs), C.c_void_p]),
     "ca_tattn_fused_supported": (C.c_int, [C.POINTER(TattnArgs)]),
     "ca_pack_w_tattn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ca_pack_w_out": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ca_xattn_fused": (C.c_int, [C.POINTER(XattnArgs), C.c_void_p]),
     "ca_xattn_fused_supported": (C.c_int, [C.POINTER(XattnArgs)]),
     "ca_xattn_pack_w": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
+from .context import dispatch
 from .layers import HipLinear, LnFold, WeightArena, ln_fold_enabled, pack_concat_rows
 
 
@@ -48,6 +49,13 @@ class AttnProcessor2_0(nn.Module):
         if ln is not None and encoder_hidden_states is None and temporal is not None and getattr(attn, "tfrag", None) is not None:
             # LayerNorm + positional encoding + q|k|v + attention over the frames in one launch where the library takes the shape
             b, f, n = temporal
+            ofrag = getattr(attn, "ofrag", None)
+            if ofrag is not None and dispatch.attn_out_fused:  # ... and the output projection + bias + residual in the same launch (ABI v12)
+                to_out = attn.to_out[0]
+                out = K.tattn_fused(x, attn.tfrag.t, attn.tgamma.t, attn.tbias_pe.t, b, f, n, attn.heads, attn.tln_eps, attn.scale,
+                                    w_out_frag=ofrag.t, bias_out=None if to_out.b is None else to_out.b.t, residual=res)
+                if out is not None:
+                    return out.reshape(B, N, C)
             o = K.tattn_fused(x, attn.tfrag.t, attn.tgamma.t, attn.tbias_pe.t, b, f, n, attn.heads, attn.tln_eps, attn.scale)
             if o is not None:
                 out = attn.to_out[0].run(o, residual=res, row_sums=row_sums)
@@ -67,6 +75,13 @@ class AttnProcessor2_0(nn.Module):
             if ent is None:
                 ent = cache[("kvf", id(attn))] = (K.xattn_pack_kv(kv, nb, L, nk, attn.scale), nk, L)
             if ent[0] is not None and ent[1] == nk:
+                ofrag = getattr(attn, "ofrag", None)
+                if ofrag is not None and dispatch.attn_out_fused:  # ... and to_out + bias + residual in the same launch (ABI v12)
+                    to_out = attn.to_out[0]
+                    out = K.xattn_fused(x, attn.xfrag.t, ln[1].b.t, ent[0], B, N, frames_per_kv, kv_mod, nk, ln[1].eps, w_out_frag=ofrag.t,
+                                        bias_out=None if to_out.b is None else to_out.b.t, residual=res)
+                    if out is not None:
+                        return out.reshape(B, N, C)
                 o = K.xattn_fused(x, attn.xfrag.t, ln[1].b.t, ent[0], B, N, frames_per_kv, kv_mod, nk, ln[1].eps)
                 if o is not None:
                     out = attn.to_out[0].run(o, residual=res, row_sums=row_sums)
@@ -202,6 +217,12 @@ class Attention(nn.Module):
         else:
             self.qkv = pack_concat_rows(arena, dtype, [self.to_q, self.to_k, self.to_v])
         self.to_out[0].pack(arena, dtype)
+        # the output projection as the last stage of the one-launch attentions (ABI v12: K.tattn_fused / K.xattn_fused with w_out_frag)
+        self.ofrag = None
+        if (self.heads, self.inner_dim, self.query_dim) == (8, 320, 320) and self.fold is not None:
+            from .layers import _f32, frag_order_wout
+            to_out = self.to_out[0]
+            self.ofrag = arena.add((102400,), dtype, lambda: frag_order_wout(_f32(to_out.weight)))
         if hasattr(self.processor, "pack"):
             self.processor.pack(arena, dtype)
 

@@ -36,6 +36,7 @@ class Dispatch:
     ff_fused = True       # ca_ff_fused for the C = 320 feed-forward
     tattn_fused = True    # ca_tattn_fused for the 64x64-latent motion modules
     xattn_fused = True    # ca_xattn_fused for the 64x64-latent text cross-attention
+    attn_out_fused = True  # ... with the output projection + bias + residual as their last stage (ABI v12)
     ln_row_sums = True    # LayerNorm statistics from the producing GEMM's epilogue
     repeat_kernel = True  # ca_repeat instead of torch.cat for the CFG-shared prefix
     ln_fold = True        # LayerNorm folded into the projection it feeds

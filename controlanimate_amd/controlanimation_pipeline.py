@@ -53,9 +53,15 @@ class ControlAnimationPipeline:
         # How far the host may run ahead of the device, in denoise steps.  An unpaced loop enqueues faster than the device
         # drains (a replay is ~3 us of host time per kernel against ~75 us of device time), fills the hardware queue and then
         # SPINS inside the runtime for the rest of every step: two cores per rank for nothing (round 4: 122 ms of CPU per
-        # 59 ms step).  With a bound the loop sleeps on a `blocking=True` HIP event (interrupt wait, no CPU) until the
-        # step `steps_in_flight` steps back has finished; 2 keeps one whole step queued behind the running one, so the device
-        # never waits for the host.  0 = unpaced (the old behaviour).  The end of a window is awaited the same way.
+        # 59 ms step).  With a bound the loop waits until the step `steps_in_flight` steps back has finished before it
+        # enqueues the next one; 2 keeps one whole step queued behind the running one, so the device never waits for the
+        # host.  HOW it waits is `pace_wait`: "sleep" polls hipEventQuery between `time.sleep(pace_poll_s)` naps -- the
+        # thread is off the CPU (measured on this pool: hipEventSynchronize spins even on a hipEventBlockingSync event, see
+        # DESIGN 5); "event" is that blocking synchronize, kept for A/B runs.  0 = unpaced (the round-4 behaviour).  The end
+        # of a window is awaited the same way.
+        self.pace_wait = "sleep"
+        self.pace_poll_s = 0.001
+        self.pace_timeout_s = 120.0
         self.steps_in_flight = 2
         self.fuse_controlnet_adds = True  # (False: separate ca_add_bcast passes, as round 2 -- A/B runs and the tests that compare the two)
         self._graph_state = None
@@ -235,12 +241,25 @@ class ControlAnimationPipeline:
         swapping or releasing models.  The next graph-mode call captures again."""
         self._graph_state = None
 
+    def _await(self, ev) -> None:
+        """Waits for a recorded pacing event without burning a core (see `steps_in_flight`)."""
+        if self.pace_wait == "event":
+            ev.synchronize()
+            return
+        nap, t0 = float(self.pace_poll_s), time.monotonic()
+        while not ev.query():
+            time.sleep(nap)
+            if time.monotonic() - t0 > self.pace_timeout_s:  # a device hang must not become a silent endless poll
+                raise RuntimeError(f"the denoise step recorded {self.pace_timeout_s:.0f} s ago has not finished (device hang?)")
+
     def _pace_event(self, i: int):
-        """Blocking HIP events of the pacing ring (created once: an event per step would be 20 create / destroy pairs per window)."""
-        ring = self.__dict__.setdefault("_pace_ring", [])
+        """Events of the pacing ring (created once: an event per step would be 20 create / destroy pairs per window).  Plain events for
+        the polling wait; hipEventBlockingSync ones only for pace_wait = "event"."""
+        kind = self.pace_wait == "event"
+        ring = self.__dict__.setdefault("_pace_ring", {}).setdefault(kind, [])
         n = max(1, int(self.steps_in_flight)) + 1
         while len(ring) < n:
-            ring.append(torch.cuda.Event(blocking=True))
+            ring.append(torch.cuda.Event(blocking=kind))
         return ring[i % n]
 
     # ---- what a captured hipGraph of the step reads besides its own pool ---------------------------------------------
@@ -475,7 +494,7 @@ class ControlAnimationPipeline:
             idx = first + i
             in_scale = sched.input_scale(idx)
             if pace_n > 0 and len(pace) >= pace_n:
-                pace.pop(0).synchronize()  # sleeps: hipEventBlockingSync
+                self._await(pace.pop(0))
             if use_graph:
                 K.latents_to_nhwc(latents, cpad, rep, in_scale, unet.act_dtype, out=gs["x"])   # [(rep f), h, w, 8]
                 gs["t"].fill_(float(t))
@@ -526,7 +545,7 @@ class ControlAnimationPipeline:
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, latents)
         if pace:  # the caller's next device read (decode, .cpu()) would spin on the stream: sleep until the window is done
-            pace[-1].synchronize()
+            self._await(pace[-1])
         final = denoised if use_lcm else latents
         if output_type == "latent" or self.vae is None:
             video = final

@@ -21,6 +21,7 @@ namespace {
 using namespace ca_gemm_detail;
 #include "ca_gemm_ar.h"
 #include "ca_ff_fused.h"
+#include "ca_attn_out.h"
 #include "ca_tattn_fused.h"
 #include "ca_xattn_fused.h"
 
@@ -119,6 +120,24 @@ extern "C" int ca_pack_w_tattn(const void* w, int32_t n, int32_t k, void* dst, v
   return CA_OK;
 }
 
+extern "C" int ca_pack_w_out(const void* w, int32_t n, int32_t k, void* dst, void* stream) {
+  CA_REQUIRE(w && dst, "ca_pack_w_out: null operand");
+  CA_REQUIRE(n == 320 && k == 320, "ca_pack_w_out: n=%d k=%d (to_out[0].weight: 320 x 320)", n, k);
+  CA_REQUIRE((((uintptr_t)w | (uintptr_t)dst) & 15) == 0, "ca_pack_w_out: operands must be 16-byte aligned");
+  static_assert(CA_WOUT_ELEMS == CA_ATTN_WOUT_FRAG_ELEMS, "header constant");
+  hipLaunchKernelGGL(k_pack_w_out, dim3((CA_WOUT_ELEMS / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u16*)w, (u16*)dst);
+  CA_CHECK_LAUNCH("ca_pack_w_out");
+  return CA_OK;
+}
+
+// the optional output stage of the one-launch attentions (ABI v12): 1 = absent or acceptable
+static int attn_out_args_ok(const void* w_out_frag, const float* bias_out, const void* residual, int64_t ld_res, int64_t rows) {
+  if (!w_out_frag) return (bias_out || residual) ? 0 : 1;  // bias / residual belong to the projection
+  if ((((uintptr_t)w_out_frag | (uintptr_t)bias_out | (uintptr_t)residual) & 15) != 0) return 0;
+  if (residual && (ld_res % 8 || ld_res < 320 || ((rows - 1) * ld_res + 320) * 2 >= 0x7FFFFF00ll)) return 0;
+  return 1;
+}
+
 extern "C" int ca_tattn_fused_supported(const ca_tattn_args* a) {
   if (!a || !a->x || !a->w_frag || !a->gamma || !a->bias_pe || !a->o) return 0;
   if (a->c != 320 || a->heads != 8 || a->frames != 16 || a->batch < 1 || a->tokens < 8 || a->tokens % 8) return 0;
@@ -130,6 +149,7 @@ extern "C" int ca_tattn_fused_supported(const ca_tattn_args* a) {
   const int64_t lim = 0x7FFFFF00ll;
   if (((rows - 1) * a->lda + 320) * 2 >= lim || ((rows - 1) * a->ldo + 320) * 2 >= lim) return 0;
   if (!(a->ln_eps > 0.f) || !(a->scale > 0.f)) return 0;
+  if (!attn_out_args_ok(a->w_out_frag, a->bias_out, a->residual, a->ld_res, rows)) return 0;
   return 1;
 }
 
@@ -153,6 +173,18 @@ extern "C" int ca_tattn_fused(const ca_tattn_args* a, void* stream) {
   const int tiles = (int)((int64_t)a->batch * a->tokens / 8);
   static const int dbg = CA_KNOB("CA_TATTN_DBG", 0);
   p.dbg = dbg;
+  if (a->w_out_frag) {  // with the output projection: one block of eight waves per CU (k_tattn_out)
+    p.out.wof = (const u16*)a->w_out_frag;
+    p.out.bias = a->bias_out;
+    p.out.res = (const u16*)a->residual;
+    p.out.ld_res = (int)a->ld_res;
+    p.out.res_bytes = a->residual ? (unsigned)(((rows - 1) * a->ld_res + 320) * 2) : 0u;
+    const unsigned grid1 = (unsigned)(tiles < ar_cu_count() ? tiles : ar_cu_count());
+    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_tattn_out<CA_BF16>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+    else hipLaunchKernelGGL((k_tattn_out<CA_F16>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+    CA_CHECK_LAUNCH("ca_tattn_fused(out)");
+    return CA_OK;
+  }
   const int slots = (dbg & 16) ? ar_cu_count() : 2 * ar_cu_count();  // (16: one block per CU -- stamps of a wave that has its SIMD to itself)
   const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
   if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_tattn_fused<CA_BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles);
@@ -196,6 +228,7 @@ extern "C" int ca_xattn_fused_supported(const ca_xattn_args* a) {
   const int64_t lim = 0x7FFFFF00ll;
   if (((int64_t)(a->m - 1) * a->lda + 320) * 2 >= lim || ((int64_t)(a->m - 1) * a->ldo + 320) * 2 >= lim) return 0;
   if (!(a->ln_eps > 0.f)) return 0;
+  if (!attn_out_args_ok(a->w_out_frag, a->bias_out, a->residual, a->ld_res, a->m)) return 0;
   return 1;
 }
 
@@ -216,6 +249,18 @@ extern "C" int ca_xattn_fused(const ca_xattn_args* a, void* stream) {
   p.o_bytes = (unsigned)(((int64_t)(a->m - 1) * a->ldo + 320) * 2);
   p.kvf_bytes = (unsigned)((int64_t)a->kv_batches * 8 * CA_XATTN_KVF_ELEMS * 2);
   const int tiles = a->m / 128;
+  if (a->w_out_frag) {  // with the output projection: one block of eight waves per CU (k_xattn_out)
+    p.out.wof = (const u16*)a->w_out_frag;
+    p.out.bias = a->bias_out;
+    p.out.res = (const u16*)a->residual;
+    p.out.ld_res = (int)a->ld_res;
+    p.out.res_bytes = a->residual ? (unsigned)(((int64_t)(a->m - 1) * a->ld_res + 320) * 2) : 0u;
+    const unsigned grid1 = (unsigned)(tiles < ar_cu_count() ? tiles : ar_cu_count());
+    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_xattn_out<CA_BF16>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+    else hipLaunchKernelGGL((k_xattn_out<CA_F16>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+    CA_CHECK_LAUNCH("ca_xattn_fused(out)");
+    return CA_OK;
+  }
   const int slots = 2 * ar_cu_count();
   const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
   if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_xattn_fused<CA_BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, tiles);

@@ -8,9 +8,9 @@ using namespace ca_gemm_detail;
 #include "ca_gemm_wres.h"
 #include "ca_gemm_ps.h"
 #include "ca_gemm_pq.h"
-#ifdef CA_EXPERIMENTS  // round-2 experiments that never became defaults: not in the product library
-#include "ca_gemm_pp.h"
-#include "ca_gemm_pp3.h"
+#ifdef CA_EXPERIMENTS  // round-2 experiments that never became defaults: csrc/experiments/, not in the product library
+#include "experiments/ca_gemm_pp.h"
+#include "experiments/ca_gemm_pp3.h"
 #endif
 
 int cu_count() {

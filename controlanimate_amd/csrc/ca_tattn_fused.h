@@ -43,6 +43,7 @@ struct TattnParams {
   float ln_eps, scale_log2;
   unsigned x_bytes, o_bytes;
   int dbg;  // (-DCA_EXPERIMENTS timing switches: 1 no LayerNorm pass, 2 no stores, 8 no tile DMA after the first)
+  AttnOutParams out;  // ABI v12: the output projection + bias + residual as the kernel's last stage (k_tattn_out)
 };
 
 constexpr int CA_TATTN_WF_ELEMS = 4 * 2 * 3 * 10 * 3 * 64 * 8;
@@ -286,5 +287,225 @@ __global__ __launch_bounds__(256, 2) void k_tattn_fused(TattnParams p, int tiles
         CA_TA_STAMP(8)
       }
     }
+  }
+}
+
+
+// ---- round 5 (ABI v12): the same attention WITH its output projection, bias and residual (ca_attn_out.h) ---------------------------
+//   y = softmax(q k^T / sqrt(d)) v Wout^T + b_out + x        (motion_module.py:212-224: `attention_block(norm(x)) + x`)
+// One block of EIGHT waves per CU (wave w = head w: one head each instead of two), the tile in one of two 80 KB buffers:
+//   top     x(t) has landed in buf[t & 1]                                                        barrier
+//   LN      LayerNorm + positional encoding in place, four threads per row                        barrier
+//   attn    waves 0..3 issue the DMA of tile t + 1 into the OTHER buffer (their first W refill then waits for it -- loads return in
+//           order -- while waves 4..7, the second wave of each SIMD, have the matrix pipes to themselves: the stall is covered);
+//           three passes of the activation-resident K loop + the attention, exactly as k_tattn_fused; o stays in registers (48)
+//           Wout chunks 0, 1 and the residual rows are requested                                  barrier (every wave has read x')
+//   o       o -> buf[t & 1] in place of x' (8-byte pieces, the tile's swizzle)                    barrier
+//   out     y = o Wout^T + b + residual, 64 x 80 per wave (ca_attn_out.h), stores
+// o never reaches HBM (84 MB written + read per launch) and the k_gemm_wres launch behind it is gone.
+template <int DT>
+__global__ __launch_bounds__(512, 2) void k_tattn_out(TattnParams p, int tiles) {
+  constexpr int K = 320, KQ = 10, TM = 8, TJ = 3, BM = 128, HD = 40;
+  constexpr int ROWB = K * 2, TILEB = BM * ROWB;
+  constexpr unsigned CHUNKB = TJ * 1024u;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILEB];
+  static_assert(2 * TILEB <= 160 * 1024, "two tile buffers");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wf, 0, (unsigned)CA_TATTN_WF_ELEMS * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.o, 0, p.o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc((void*)p.out.wof, 0, (unsigned)CA_WOUT_ELEMS * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out.bias ? (const void*)p.out.bias : (const void*)p.wf), 0, p.out.bias ? 320u * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out.res ? (const void*)p.out.res : (const void*)p.wf), 0, p.out.res ? p.out.res_bytes : 0u, 0x00020000);
+
+  const int f_sw = (l15 >> 1) & 7;
+  const int fa_lane = l15 * ROWB + (((f_sw >> 2) << 2) + (g ^ (f_sw & 3))) * 16;
+  int fa_b[2][2] = {{fa_lane, fa_lane ^ 64}, {fa_lane + 4 * 16 * ROWB, (fa_lane ^ 64) + 4 * 16 * ROWB}};
+  asm volatile("" : "+v"(fa_b[0][0]), "+v"(fa_b[0][1]), "+v"(fa_b[1][0]), "+v"(fa_b[1][1]));
+
+  // tile DMA by waves 0..3, 20 wave instructions (1 KB of the tile image) each
+  auto issue_tile = [&](int tile, int bufsel) __attribute__((always_inline)) {
+    if (wid >= 4) return;
+    const int g0 = tile * 8;
+    const int bimg = g0 / p.hw, pix0 = g0 - bimg * p.hw;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+#pragma unroll
+    for (int q = 0; q < 20; ++q) {
+      const unsigned idx = (unsigned)((wid * 20 + q) * 64 + lane_o);
+      const unsigned r = __umulhi(idx >> 3, 0xCCCCCCCDu) >> 2;  // idx / 40: LDS row = 16 * pixel + frame
+      const unsigned cp = idx - r * 40u;
+      const unsigned c = cp ^ ((r >> 1) & 7u);
+      const unsigned grow = (unsigned)((bimg * 16 + (int)(r & 15u)) * p.hw + pix0) + (r >> 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + bufsel * TILEB + (wid * 20 + q) * 1024), 16,
+                                               grow * (unsigned)p.lda * 2u + c * 16u, 0, 0, 0);
+    }
+  };
+
+  if ((int)blockIdx.x < tiles) issue_tile(blockIdx.x, 0);
+  int it = 0;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x, ++it) {
+    const int cur = it & 1;
+    unsigned char* const xb = smem + cur * TILEB;
+    const int g0 = tile * 8;
+    const int bimg = g0 / p.hw, pix0 = g0 - bimg * p.hw;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // x(tile) has landed; every wave is past the previous tile's output stage
+    {  // LayerNorm + positional encoding in place: four threads per row, 10 pieces each
+      const int r = tid >> 2, h = tid & 3;
+      const int fs = (r >> 1) & 7;
+      unsigned char* src = xb + r * ROWB + h * 160;
+      const float* bprow = p.bp + (int64_t)(r & 15) * p.ld_bp;
+      float s = 0.f, ss = 0.f;
+#pragma unroll 5
+      for (int q = 0; q < 10; ++q) {
+        const u32x4 v = ld16(src + q * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = Elem<DT>::to_f((u16)(v[e] & 0xffffu)), a1 = Elem<DT>::to_f((u16)(v[e] >> 16));
+          s += a0 + a1;
+          ss = fmaf(a0, a0, fmaf(a1, a1, ss));
+        }
+      }
+      s += __shfl_xor(s, 1);
+      ss += __shfl_xor(ss, 1);
+      s += __shfl_xor(s, 2);
+      ss += __shfl_xor(ss, 2);
+      const float mean = s * (1.f / K);
+      const float rstd = rsqrtf(fmaxf(ss * (1.f / K) - mean * mean, 0.f) + p.ln_eps);
+      const float nb = -mean * rstd;
+#pragma unroll 5
+      for (int q = 0; q < 10; ++q) {
+        u32x4 v = ld16(src + q * 16);
+        const int col = (((h * 10 + q) ^ fs)) * 8;  // logical chunk of physical piece h * 10 + q
+        const float4 g0v = *reinterpret_cast<const float4*>(p.gamma + col), g1v = *reinterpret_cast<const float4*>(p.gamma + col + 4);
+        const float4 b0v = *reinterpret_cast<const float4*>(bprow + col), b1v = *reinterpret_cast<const float4*>(bprow + col + 4);
+        const float gm[8] = {g0v.x, g0v.y, g0v.z, g0v.w, g1v.x, g1v.y, g1v.z, g1v.w};
+        const float bb[8] = {b0v.x, b0v.y, b0v.z, b0v.w, b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = Elem<DT>::to_f((u16)(v[e] & 0xffffu)), a1 = Elem<DT>::to_f((u16)(v[e] >> 16));
+          v[e] = pack2<DT>(fmaf(fmaf(a0, rstd, nb), gm[2 * e], bb[2 * e]), fmaf(fmaf(a1, rstd, nb), gm[2 * e + 1], bb[2 * e + 1]));
+        }
+        st16(src + q * 16, v);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the table loads of the pass: nothing of this wave is in flight when the DMA is queued)
+    __syncthreads();
+
+    int lane_k = lane;
+    asm volatile("" : "+v"(lane_k));
+    const unsigned wv = (unsigned)lane_k * 16u;
+    const unsigned whead = (unsigned)((wid & 3) * 2 + (wid >> 2)) * (30u * CHUNKB);  // head = wid: ca_pack_w_tattn keeps heads w, w + 4 adjacent
+    u32x4 fa[TM], fb[2][TJ];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fb[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, whead + (unsigned)(c * TJ + j) * 1024u, 0));
+    {
+      const int next = tile + (int)gridDim.x;
+      if (next < tiles) issue_tile(next, cur ^ 1);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = ld16(xb + fa_b[i >> 2][0] + (i & 3) * 16 * ROWB);
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto kloop = [&](auto pass_c, f32x4(&acc)[TM][TJ]) __attribute__((always_inline)) {
+      constexpr int PS = decltype(pass_c)::value;
+#pragma unroll
+      for (int kq = 0; kq < KQ; ++kq) {
+        const int nk = (kq + 1) % KQ;
+        const int fa_off = (nk >> 1) * 128;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const f32x4 c0 = kq == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j];
+            if (PS == 2) acc[i][j] = Elem<DT>::mfma(fa[i], fb[kq & 1][j], c0);
+            else acc[i][j] = Elem<DT>::mfma(fb[kq & 1][j], fa[i], c0);
+            if (j == TJ - 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              fa[i] = ld16(xb + fa_b[i >> 2][nk & 1] + fa_off + (i & 3) * 16 * ROWB);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          const int sn = PS * 10 + kq + 2;  // stream position (chunks of this head) of the refill
+          if (sn < 30) fb[kq & 1][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, whead + (unsigned)(sn * TJ + j) * 1024u, 0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+
+    u32x2 qp[TM][TJ];
+    {
+      f32x4 acc[TM][TJ];
+      kloop(IntC<0>{}, acc);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          qp[i][j] = (u32x2){pack2<DT>(acc[i][j][0] * p.scale_log2, acc[i][j][1] * p.scale_log2), pack2<DT>(acc[i][j][2] * p.scale_log2, acc[i][j][3] * p.scale_log2)};
+    }
+    u32x2 pp[TM];
+    {
+      f32x4 acc[TM][TJ];
+      kloop(IntC<1>{}, acc);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};  // S^T[key = 4 g + r][query = l15] in the exp2 domain
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const u32x2 kp = {pack2<DT>(acc[i][j][0], acc[i][j][1]), pack2<DT>(acc[i][j][2], acc[i][j][3])};
+          st = Elem<DT>::mfma16(kp, qp[i][j], st);
+        }
+        const float m = rowgroup_max(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(st[r] - m);
+        const float inv = __builtin_amdgcn_rcpf(rowgroup_sum((e[0] + e[1]) + (e[2] + e[3])));
+        pp[i] = (u32x2){pack2<DT>(e[0] * inv, e[1] * inv), pack2<DT>(e[2] * inv, e[3] * inv)};
+      }
+    }
+    u32x2 op[TM][TJ];  // O^T[d_v = 16 j + 4 g + r][query = frame l15] of pixel i, rounded to the activation type
+    {
+      f32x4 acc[TM][TJ];
+      kloop(IntC<2>{}, acc);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const u32x2 vp = {pack2<DT>(acc[i][j][0], acc[i][j][1]), pack2<DT>(acc[i][j][2], acc[i][j][3])};
+          const f32x4 ot = Elem<DT>::mfma16(vp, pp[i], (f32x4){0.f, 0.f, 0.f, 0.f});
+          op[i][j] = (u32x2){pack2<DT>(ot[0], ot[1]), pack2<DT>(ot[2], ot[3])};
+        }
+    }
+    // output stage: its first W chunks and the residual rows are requested before the barriers
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int l15e = lane_e & 15, ge = lane_e >> 4;
+    const unsigned row_base = (unsigned)((bimg * 16 + l15e) * p.hw + pix0) + (unsigned)((wid >> 2) * 4);  // pixel 4 rh + i of frame l15: rows one apart
+    AttnOutRegs R;
+    attn_out_prefetch<DT>(R, p.out, rs_wo, rs_res, wid, lane_e, row_base, 1u);
+    __syncthreads();  // every wave has finished its K loops on x'
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int dv = 16 * j + 4 * ge;
+        if (dv < HD) {
+          const int col = wid * HD + dv;
+          *reinterpret_cast<u32x2*>(xb + (16 * i + l15e) * ROWB + (((col >> 3) ^ ((l15e >> 1) & 7)) << 4) + (col & 7) * 2) = op[i][j];
+        }
+      }
+    __syncthreads();  // the o tile is complete
+    attn_out_run<DT>(R, xb, fa_b, p.out, rs_wo, rs_bo, rs_o, wid, lane_e, row_base, 1u, (unsigned)p.ldo);
   }
 }

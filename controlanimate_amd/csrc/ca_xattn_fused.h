@@ -27,6 +27,7 @@ struct XattnParams {
   int m, tokens, frames_per_kv, kv_mod, nk;
   float ln_eps;
   unsigned x_bytes, o_bytes, kvf_bytes;
+  AttnOutParams out;  // ABI v12: the output projection + bias + residual as the kernel's last stage (k_xattn_out)
 };
 
 constexpr int CA_XATTN_WF_ELEMS = 4 * 2 * 10 * 3 * 64 * 8;  // 122880
@@ -269,5 +270,230 @@ __global__ __launch_bounds__(256, 2) void k_xattn_fused(XattnParams p, int tiles
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+}
+
+
+// ---- round 5 (ABI v12): the same attention WITH its output projection, bias and residual (ca_attn_out.h) ---------------------------
+//   y = softmax(q K^T / sqrt(d)) V Wout^T + b_out + x        (animatediff/models/attention.py:253-262: `attn2(norm2(x), ehs) + x`)
+// The structure of k_tattn_out (ca_tattn_fused.h): one block of eight waves per CU, wave w = head w, the tile in one of two 80 KB
+// buffers (the next tile's DMA issued by waves 0..3 at the start of the K loops), o through LDS into the 64 x 80-per-wave output stage.
+template <int DT>
+__global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) {
+  constexpr int K = 320, KQ = 10, TM = 8, TJ = 3, BM = 128, HD = 40, KT = 5;
+  constexpr int ROWB = K * 2, TILEB = BM * ROWB;
+  constexpr unsigned CHUNKB = TJ * 1024u;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILEB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wf, 0, (unsigned)CA_XATTN_WF_ELEMS * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.o, 0, p.o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc((void*)p.kvf, 0, p.kvf_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.wf), 0, p.bias ? 320u * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc((void*)p.out.wof, 0, (unsigned)CA_WOUT_ELEMS * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out.bias ? (const void*)p.out.bias : (const void*)p.wf), 0, p.out.bias ? 320u * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out.res ? (const void*)p.out.res : (const void*)p.wf), 0, p.out.res ? p.out.res_bytes : 0u, 0x00020000);
+
+  const int f_sw = (l15 >> 1) & 7;
+  const int fa_lane = l15 * ROWB + (((f_sw >> 2) << 2) + (g ^ (f_sw & 3))) * 16;
+  int fa_b[2][2] = {{fa_lane, fa_lane ^ 64}, {fa_lane + 4 * 16 * ROWB, (fa_lane ^ 64) + 4 * 16 * ROWB}};
+  asm volatile("" : "+v"(fa_b[0][0]), "+v"(fa_b[0][1]), "+v"(fa_b[1][0]), "+v"(fa_b[1][1]));
+
+  auto issue_tile = [&](int tile, int bufsel) __attribute__((always_inline)) {
+    if (wid >= 4) return;
+    const int m0 = tile * BM;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+#pragma unroll
+    for (int q = 0; q < 20; ++q) {
+      const unsigned idx = (unsigned)((wid * 20 + q) * 64 + lane_o);
+      const unsigned r = __umulhi(idx >> 3, 0xCCCCCCCDu) >> 2;  // idx / 40
+      const unsigned cp = idx - r * 40u;
+      const unsigned c = cp ^ ((r >> 1) & 7u);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + bufsel * TILEB + (wid * 20 + q) * 1024), 16,
+                                               (unsigned)(m0 + (int)r) * (unsigned)p.lda * 2u + c * 16u, 0, 0, 0);  // (m % 128 == 0: every tile is whole)
+    }
+  };
+
+  if ((int)blockIdx.x < tiles) issue_tile(blockIdx.x, 0);
+  int it = 0;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x, ++it) {
+    const int cur = it & 1;
+    unsigned char* const xb = smem + cur * TILEB;
+    const int m0 = tile * BM;
+    const int zk = ((m0 / p.tokens) / p.frames_per_kv) % p.kv_mod;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {  // LayerNorm in place (gamma / beta live in Wq and the bias): four threads per row, 10 pieces each
+      const int r = tid >> 2, h = tid & 3;
+      unsigned char* src = xb + r * ROWB + h * 160;
+      float s = 0.f, ss = 0.f;
+#pragma unroll 5
+      for (int q = 0; q < 10; ++q) {
+        const u32x4 v = ld16(src + q * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = Elem<DT>::to_f((u16)(v[e] & 0xffffu)), a1 = Elem<DT>::to_f((u16)(v[e] >> 16));
+          s += a0 + a1;
+          ss = fmaf(a0, a0, fmaf(a1, a1, ss));
+        }
+      }
+      s += __shfl_xor(s, 1);
+      ss += __shfl_xor(ss, 1);
+      s += __shfl_xor(s, 2);
+      ss += __shfl_xor(ss, 2);
+      const float mean = s * (1.f / K);
+      const float rstd = rsqrtf(fmaxf(ss * (1.f / K) - mean * mean, 0.f) + p.ln_eps);
+      const float nb = -mean * rstd;
+#pragma unroll 5
+      for (int q = 0; q < 10; ++q) {
+        u32x4 v = ld16(src + q * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = Elem<DT>::to_f((u16)(v[e] & 0xffffu)), a1 = Elem<DT>::to_f((u16)(v[e] >> 16));
+          v[e] = pack2<DT>(fmaf(a0, rstd, nb), fmaf(a1, rstd, nb));
+        }
+        st16(src + q * 16, v);
+      }
+    }
+    __syncthreads();
+
+    int lane_k = lane;
+    asm volatile("" : "+v"(lane_k));
+    const unsigned wv = (unsigned)lane_k * 16u;
+    const int head = wid;
+    const unsigned whead = (unsigned)((wid & 3) * 2 + (wid >> 2)) * (10u * CHUNKB);  // ca_xattn_pack_w keeps heads w, w + 4 adjacent
+    const unsigned kvb = (unsigned)(zk * 8 + head) * (unsigned)(CA_XATTN_KVF_ELEMS * 2) + (unsigned)lane_k * 8u;
+    u32x4 fa[TM], fb[2][TJ];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fb[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, whead + (unsigned)(c * TJ + j) * 1024u, 0));
+    {
+      const int next = tile + (int)gridDim.x;
+      if (next < tiles) issue_tile(next, cur ^ 1);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = ld16(xb + fa_b[i >> 2][0] + (i & 3) * 16 * ROWB);
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x2 kf[KT][TJ], vf[TJ][KT];
+    u32x2 op[TM][TJ];
+    {
+      f32x4 acc[TM][TJ];
+#pragma unroll
+      for (int kq = 0; kq < KQ; ++kq) {
+        const int nk = (kq + 1) % KQ;
+        const int fa_off = (nk >> 1) * 128;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const f32x4 c0 = kq == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j];
+            acc[i][j] = Elem<DT>::mfma(fb[kq & 1][j], fa[i], c0);
+            if (j == TJ - 1 && kq + 1 < KQ) {
+              __builtin_amdgcn_sched_barrier(0);
+              fa[i] = ld16(xb + fa_b[i >> 2][nk & 1] + fa_off + (i & 3) * 16 * ROWB);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kq + 2 < KQ) fb[kq & 1][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv, whead + (unsigned)((kq + 2) * TJ + j) * 1024u, 0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kq == KQ - 2) {  // the head's K fragments, under the last two chunks
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) kf[kt][c] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_kv, kvb, (unsigned)((kt * 3 + c) * 512), 0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      int lane_q = lane;
+      asm volatile("" : "+v"(lane_q));
+      const int gq = lane_q >> 4;
+      u32x2 qp[TM][TJ];
+      {
+        f32x4 bi[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) vf[j][kt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_kv, kvb, (unsigned)((15 + j * 5 + kt) * 512), 0));
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bi, (unsigned)(head * HD + 16 * j + 4 * gq) * 4u, 0, 0));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            qp[i][j] = (u32x2){pack2<DT>(acc[i][j][0] + bi[j][0], acc[i][j][1] + bi[j][1]), pack2<DT>(acc[i][j][2] + bi[j][2], acc[i][j][3] + bi[j][3])};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        f32x4 st[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          st[kt] = Elem<DT>::mfma16(kf[kt][0], qp[i][0], (f32x4){0.f, 0.f, 0.f, 0.f});
+          st[kt] = Elem<DT>::mfma16(kf[kt][1], qp[i][1], st[kt]);
+          st[kt] = Elem<DT>::mfma16(kf[kt][2], qp[i][2], st[kt]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt >= 4 && 16 * kt + 4 * gq + r >= p.nk) st[kt][r] = -INFINITY;
+        float m = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+#pragma unroll
+        for (int kt = 1; kt < KT; ++kt) m = fmaxf(m, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
+        m = rowgroup_max(m);
+        float l = 0.f;
+        u32x2 pp[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          float e[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            e[r] = __builtin_amdgcn_exp2f(st[kt][r] - m);
+            l += e[r];
+          }
+          pp[kt] = (u32x2){pack2_prob<DT>(e[0], e[1]), pack2_prob<DT>(e[2], e[3])};
+        }
+        const float inv = __builtin_amdgcn_rcpf(rowgroup_sum(l));
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          f32x4 ot = Elem<DT>::mfma16(vf[j][0], pp[0], (f32x4){0.f, 0.f, 0.f, 0.f});  // O^T[d_v = 16 j + 4 g + r][row = l15]
+#pragma unroll
+          for (int kt = 1; kt < KT; ++kt) ot = Elem<DT>::mfma16(vf[j][kt], pp[kt], ot);
+          op[i][j] = (u32x2){pack2<DT>(ot[0] * inv, ot[1] * inv), pack2<DT>(ot[2] * inv, ot[3] * inv)};
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int l15e = lane_e & 15, ge = lane_e >> 4;
+    const unsigned row_base = (unsigned)(m0 + (wid >> 2) * 64 + l15e);
+    AttnOutRegs R;
+    attn_out_prefetch<DT>(R, p.out, rs_wo, rs_res, wid, lane_e, row_base, 16u);
+    __syncthreads();  // every wave has finished its K loop on the normalised tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int dv = 16 * j + 4 * ge;
+        if (dv < HD) {
+          const int col = head * HD + dv;
+          *reinterpret_cast<u32x2*>(xb + (16 * i + l15e) * ROWB + (((col >> 3) ^ ((l15e >> 1) & 7)) << 4) + (col & 7) * 2) = op[i][j];
+        }
+      }
+    __syncthreads();  // the o tile is complete
+    attn_out_run<DT>(R, xb, fa_b, p.out, rs_wo, rs_bo, rs_o, wid, lane_e, row_base, 16u, (unsigned)p.ldo);
   }
 }

@@ -171,24 +171,32 @@ def ff_fused(x: torch.Tensor, w1_frag: torch.Tensor, bias1: torch.Tensor, colsum
 
 
 def tattn_fused(x: torch.Tensor, w_frag: torch.Tensor, gamma: torch.Tensor, bias_pe: torch.Tensor, b: int, frames: int, tokens: int,
-                heads: int, ln_eps: float, scale: float) -> Optional[torch.Tensor]:
+                heads: int, ln_eps: float, scale: float, *, w_out_frag: Optional[torch.Tensor] = None, bias_out: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """o = softmax(q k^T scale) v over the frame axis with q|k|v = (LayerNorm(x) + pe[frame]) Wqkv^T in one launch (ca_tattn_fused,
     ABI v10: the motion modules of the 64x64-latent level) -- or None where the library does not take the arguments (the caller
-    then runs the folded q|k|v GEMM and attention_temporal).  x rows in (b f n) order; bias_pe [>= frames, C] fp32."""
+    then runs the folded q|k|v GEMM and attention_temporal).  x rows in (b f n) order; bias_pe [>= frames, C] fp32.
+    With w_out_frag (layers.frag_order_wout of to_out[0].weight; ABI v12) the launch also applies the output projection and returns
+    y = o Wout^T + bias_out + residual."""
     if not dispatch.tattn_fused:
         return None
-    _req_cuda(x, w_frag, gamma, bias_pe)
+    _req_cuda(x, w_frag, gamma, bias_pe, w_out_frag, bias_out, residual)
     if x.dim() != 2 or x.stride(1) != 1 or x.shape[0] != b * frames * tokens or bias_pe.shape[0] < frames or bias_pe.stride(1) != 1:
+        return None
+    if w_out_frag is None and (bias_out is not None or residual is not None):
+        return None
+    if residual is not None and (residual.shape != x.shape or residual.stride(1) != 1 or residual.dtype != x.dtype):
         return None
     c = x.shape[1]
     o = torch.empty((x.shape[0], c), device=x.device, dtype=x.dtype)
     args = TattnArgs(x=_p(x), w_frag=_p(w_frag), gamma=_p(gamma), bias_pe=_p(bias_pe), o=_p(o), lda=x.stride(0), ldo=o.stride(0),
                      ld_bias_pe=bias_pe.stride(0), batch=b, frames=frames, tokens=tokens, heads=heads, c=c, ln_eps=float(ln_eps),
-                     scale=float(scale), dtype=dt_code(x.dtype))
+                     scale=float(scale), dtype=dt_code(x.dtype), w_out_frag=_p(w_out_frag), bias_out=_p(bias_out), residual=_p(residual),
+                     ld_res=residual.stride(0) if residual is not None else 0)
     if not lib().ca_tattn_fused_supported(C.byref(args)):
         return None
     if _plan_sink is not None:
-        _plan_sink.append("tattn_fused128")
+        _plan_sink.append("tattn_out128" if w_out_frag is not None else "tattn_fused128")
     check(lib().ca_tattn_fused(C.byref(args), _stream()), "ca_tattn_fused")
     return o
 
@@ -208,26 +216,34 @@ def xattn_pack_kv(kv: torch.Tensor, kv_batches: int, rows_per_batch: int, nk: in
 
 
 def xattn_fused(x: torch.Tensor, wq_frag: torch.Tensor, bias: Optional[torch.Tensor], kv_frag: torch.Tensor, images: int, tokens: int,
-                frames_per_kv: int, kv_mod: int, nk: int, ln_eps: float) -> Optional[torch.Tensor]:
+                frames_per_kv: int, kv_mod: int, nk: int, ln_eps: float, *, w_out_frag: Optional[torch.Tensor] = None,
+                bias_out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """o = softmax(q K^T scale) V with q = LayerNorm(x) Wq^T + bias in one launch (ca_xattn_fused, ABI v11: the text cross-attention of
     the 64x64-latent level) -- or None where the library does not take the arguments (the caller then runs the folded q GEMM and
     attention_cross).  kv_frag from xattn_pack_kv; image z uses its text batch (z // frames_per_kv) % kv_mod, kv_mod = 0 meaning `images`
-    exactly as attention_cross does (the library refuses a launch that would index past the packed text batches)."""
+    exactly as attention_cross does (the library refuses a launch that would index past the packed text batches).
+    With w_out_frag (layers.frag_order_wout of to_out[0].weight; ABI v12) the launch also applies the output projection and returns
+    y = o Wout^T + bias_out + residual."""
     if not dispatch.xattn_fused or kv_frag is None:
         return None
-    _req_cuda(x, wq_frag, bias, kv_frag)
+    _req_cuda(x, wq_frag, bias, kv_frag, w_out_frag, bias_out, residual)
     if x.dim() != 2 or x.stride(1) != 1 or x.shape[0] != images * tokens:
+        return None
+    if w_out_frag is None and (bias_out is not None or residual is not None):
+        return None
+    if residual is not None and (residual.shape != x.shape or residual.stride(1) != 1 or residual.dtype != x.dtype):
         return None
     assert kv_frag.dtype == x.dtype and wq_frag.dtype == x.dtype, "ca_xattn_fused: x, the packed Wq and the packed K/V must share one dtype"
     c = x.shape[1]
     o = torch.empty((x.shape[0], c), device=x.device, dtype=x.dtype)
     args = XattnArgs(x=_p(x), wq_frag=_p(wq_frag), bias=_p(bias), kv_frag=_p(kv_frag), o=_p(o), lda=x.stride(0), ldo=o.stride(0), m=x.shape[0],
                      tokens=tokens, frames_per_kv=frames_per_kv, kv_mod=kv_mod if kv_mod > 0 else images, kv_batches=kv_frag.shape[0],
-                     nk=nk, heads=8, c=c, ln_eps=float(ln_eps), dtype=dt_code(x.dtype))
+                     nk=nk, heads=8, c=c, ln_eps=float(ln_eps), dtype=dt_code(x.dtype), w_out_frag=_p(w_out_frag), bias_out=_p(bias_out),
+                     residual=_p(residual), ld_res=residual.stride(0) if residual is not None else 0)
     if not lib().ca_xattn_fused_supported(C.byref(args)):
         return None
     if _plan_sink is not None:
-        _plan_sink.append("xattn_fused128")
+        _plan_sink.append("xattn_out128" if w_out_frag is not None else "xattn_fused128")
     check(lib().ca_xattn_fused(C.byref(args), _stream()), "ca_xattn_fused")
     return o
 

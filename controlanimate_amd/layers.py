@@ -132,6 +132,19 @@ def frag_order_xattn(wq: torch.Tensor) -> torch.Tensor:
     return x.permute(1, 0, 4, 2, 5, 3, 6).reshape(-1).contiguous()  # [wv, hi, kq, j, g, i, e]
 
 
+def frag_order_wout(w: torch.Tensor) -> torch.Tensor:
+    """[320, 320] (an attention's to_out[0].weight at C = 320) -> the flat order ca_tattn_args.w_out_frag / ca_xattn_args.w_out_frag take
+    (= ca_pack_w_out, csrc/ca_attn_out.h): 16-byte piece L of column tile j (5 per 80-column group) of 32-deep chunk kq of column group
+    cg holds W[cg * 80 + col5(j, L & 15)][kq * 32 + (L >> 4) * 8 : + 8]."""
+    assert tuple(w.shape) == (320, 320)
+    j = torch.arange(5).view(5, 1)
+    i = torch.arange(16).view(1, 16)
+    col = torch.where(j == 4, 64 + i, 32 * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3))  # [j, i]
+    rows = (torch.arange(4).view(4, 1, 1) * 80 + col.view(1, 5, 16)).to(w.device)                # [cg, j, i]
+    x = w[rows.reshape(-1)].view(4, 5, 16, 10, 4, 8)  # [cg, j, i = L & 15, kq, g = L >> 4, e]
+    return x.permute(0, 3, 1, 4, 2, 5).reshape(-1).contiguous()  # [cg, kq, j, g, i, e]
+
+
 def frag_wanted(n: int, k: int) -> bool:
     """The shapes the activation-resident kernel takes (ca_gemm.hip ar_eligible): K = 320, N a multiple of 320, N >= 960."""
     return k == 320 and n % 320 == 0 and n >= 960

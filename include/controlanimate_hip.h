@@ -183,9 +183,22 @@ typedef struct ca_tattn_args {
   int32_t batch, frames, tokens, heads, c;
   float ln_eps, scale;  /* scale = head_dim ** -0.5 */
   int32_t dtype;
+  /* ABI v12: the attention's output projection, bias and residual in the SAME launch (motion_module.py:212-224,
+   * `attention_block(norm(x)) + x`; modules/attention_processor.py:258-270 to_out[0]):  `o` then receives
+   *   y = o Wout^T + bias_out + residual        instead of the attention output.
+   * w_out_frag: CA_ATTN_WOUT_FRAG_ELEMS elements written by ca_pack_w_out(Wout [c, c]); NULL = no output stage (as ABI v10).
+   * bias_out [c] fp32 or NULL; residual rows at stride ld_res (same row order as x / o) or NULL. */
+  const void* w_out_frag;
+  const float* bias_out;
+  const void* residual;
+  int64_t ld_res;
 } ca_tattn_args;
 int ca_tattn_fused(const ca_tattn_args* args, void* stream);
 int ca_tattn_fused_supported(const ca_tattn_args* args);
+/* ABI v12: dst[CA_ATTN_WOUT_FRAG_ELEMS] = w[320, 320] (an attention's to_out[0].weight) in the fragment order the output stage of
+ * ca_tattn_fused / ca_xattn_fused streams (ca_tattn_args.w_out_frag); 16-bit elements, 16-byte aligned. */
+#define CA_ATTN_WOUT_FRAG_ELEMS 102400
+int ca_pack_w_out(const void* w, int32_t n, int32_t k, void* dst, void* stream);
 /* dst[CA_TATTN_W_FRAG_ELEMS] = w[960, 320] (rows Wq, Wk, Wv) in the fragment order ca_tattn_args.w_frag takes (head dim 40
  * padded to 48 with zero rows; 16-bit elements, 16-byte aligned). */
 int ca_pack_w_tattn(const void* w, int32_t n, int32_t k, void* dst, void* stream);
@@ -209,6 +222,12 @@ typedef struct ca_xattn_args {
   int32_t m, tokens, frames_per_kv, kv_mod, kv_batches, nk, heads, c;
   float ln_eps;
   int32_t dtype;
+  /* ABI v12: output projection + bias + residual in the same launch, as ca_tattn_args (animatediff/models/attention.py:253-262
+   * `attn2(norm2(hidden)) + hidden`).  w_out_frag NULL = no output stage (as ABI v11). */
+  const void* w_out_frag;
+  const float* bias_out;
+  const void* residual;
+  int64_t ld_res;
 } ca_xattn_args;
 int ca_xattn_fused(const ca_xattn_args* args, void* stream);
 int ca_xattn_fused_supported(const ca_xattn_args* args);

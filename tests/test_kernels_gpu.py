@@ -773,6 +773,42 @@ def test_tattn_fused_c320(dt, tol):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.2e-2)])
+def test_tattn_fused_with_output_projection_c320(dt, tol):
+    """ca_tattn_fused with w_out_frag (ABI v12): the attention, its output projection, bias and residual in one launch -- against fp32
+    torch (motion_module.py:212-224: `attention_block(norm(x)) + x`) and against the two launches it replaces (ca_tattn_fused + ca_gemm);
+    the library's packing against layers.frag_order_wout; bit-reproducible."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import tattn_check as T
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.layers import frag_order_wout
+    for (b, tokens, lda, res) in [(2, 1024, 320, True), (1, 1032, 640, True), (2, 4096, 320, True), (1, 1024, 320, False)]:
+        x, w, gamma, beta, pe = T.make(b, tokens, dt, lda=lda)
+        wo, bo = T.make_out(dt)
+        ref = T.reference(x, w, gamma, beta, pe, b, tokens) @ wo.float().t() + bo[None, :] + (x.float() if res else 0.0)
+        wol = torch.empty(102400, device="cuda", dtype=dt)
+        K.check(K.lib().ca_pack_w_out(wo.data_ptr(), 320, 320, wol.data_ptr(), K._stream()), "ca_pack_w_out")
+        assert torch.equal(wol, frag_order_wout(wo.float()).to(dt))
+        K._plan_sink = labels = []
+        try:
+            y = T.fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, wofrag=wol, residual=res)
+        finally:
+            K._plan_sink = None
+        assert y is not None and labels == ["tattn_out128"], "the library must take this shape"
+        assert torch.equal(y, T.fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, wofrag=wol, residual=res))
+        rel = ((y.float() - ref).norm() / ref.norm()).item()
+        old = T.two_launch_out(x, w, gamma, beta, pe, b, tokens, wo, bo, residual=res)
+        rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+        assert rel < tol and rel < 1.5 * rel_old + 1e-4, (rel, rel_old)
+    # a bias or a residual without the projection is refused, not silently dropped
+    x, w, gamma, beta, pe = T.make(2, 1024, dt)
+    bp = (pe + beta[None, :]).contiguous()
+    from controlanimate_amd.layers import frag_order_tattn
+    assert K.tattn_fused(x, frag_order_tattn(w.float()).to(dt), gamma.contiguous(), bp, 2, 16, 1024, 8, 1e-5, 40 ** -0.5, residual=x) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.2e-2)])
 def test_xattn_fused_c320(dt, tol):
     """ca_xattn_fused (ABI v11): LayerNorm + to_q + attention over the text tokens in one launch, against fp32 torch and against the
     two launches it replaces; the library's packing kernels against layers.frag_order_xattn; K / V fragments repacked in place."""
@@ -807,3 +843,29 @@ def test_xattn_fused_c320(dt, tol):
     x, wq, gamma, beta, kv = X.make(2, 1024, 77, 1, dt)
     assert X.fused(x, wq, gamma, beta, kv, 2, 1024, 77, 77, 1, 1) is None
     assert K.xattn_pack_kv(kv, 1, 77, 64, 40 ** -0.5) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.2e-2)])
+def test_xattn_fused_with_output_projection_c320(dt, tol):
+    """ca_xattn_fused with w_out_frag (ABI v12): text cross-attention + to_out + bias + residual in one launch -- against fp32 torch
+    (animatediff/models/attention.py:253-262, modules/attention_processor.py:258-270) and against the two launches it replaces."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import xattn_check as X
+    from controlanimate_amd import kernels as K
+    for (images, tokens, L, nk, fpk, kvb, lda, res) in [(8, 2048, 77, 77, 4, 2, 320, True), (6, 3072, 81, 77, 2, 3, 640, True), (16, 1024, 70, 70, 8, 2, 320, False)]:
+        x, wq, gamma, beta, kv = X.make(images, tokens, L, kvb, dt, lda=lda)
+        wo, bo = X.make_out(dt)
+        ref = X.reference(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, dt) @ wo.float().t() + bo[None, :] + (x.float() if res else 0.0)
+        K._plan_sink = labels = []
+        try:
+            y = X.fused_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, bo, residual=res)
+        finally:
+            K._plan_sink = None
+        assert y is not None and labels == ["xattn_out128"], "the library must take this shape"
+        assert torch.equal(y, X.fused_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, bo, residual=res))
+        rel = ((y.float() - ref).norm() / ref.norm()).item()
+        old = X.two_launch_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, bo, residual=res)
+        rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+        assert rel < tol and rel < 1.5 * rel_old + 1e-4, (rel, rel_old)

@@ -11,6 +11,7 @@ ENV = {
     "CA_FF_FUSED": "ff_fused",
     "CA_TATTN_FUSED": "tattn_fused",
     "CA_XATTN_FUSED": "xattn_fused",
+    "CA_ATTN_OUT_FUSED": "attn_out_fused",
     "CA_LN_ROWSUMS": "ln_row_sums",
     "CA_REPEAT_KERNEL": "repeat_kernel",
     "CA_LN_FOLD": "ln_fold",

@@ -9,7 +9,8 @@ def read(path, counter):
     out = {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]
+            k = re.sub(r"^void ", "", r["Kernel_Name"])
+            k = k[:k.index(">(") + 1] if ">(" in k else k.split("(")[0]  # (template arguments may hold parentheses: __vector(4))
             out[k] = out.get(k, 0.0) + float(r["Counter_Value"])
     return out
 

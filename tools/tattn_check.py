@@ -63,6 +63,61 @@ def fused(x, w, gamma, beta, pe, b, tokens, wfrag=None):
     return K.tattn_fused(x, wfrag, gamma.contiguous(), bp, b, FR, tokens, HEADS, 1e-5, D ** -0.5)
 
 
+def make_out(dt, seed=11):
+    """to_out[0] of the attention: weight [320, 320], bias [320]."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    wo = (torch.randn(CH, CH, generator=g) * CH ** -0.5 * 1.5).to(dev).to(dt)
+    bo = (torch.randn(CH, generator=g) * 0.1).to(dev)
+    return wo, bo
+
+
+def fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, wfrag=None, wofrag=None, residual=True):
+    """ABI v12: attention + output projection + bias + residual (the block's own input) in one launch."""
+    from controlanimate_amd.layers import frag_order_wout
+    if wfrag is None:
+        wfrag = frag_order_tattn(w.float()).to(x.dtype)
+    if wofrag is None:
+        wofrag = frag_order_wout(wo.float()).to(x.dtype)
+    bp = (pe + beta[None, :]).contiguous()
+    return K.tattn_fused(x, wfrag, gamma.contiguous(), bp, b, FR, tokens, HEADS, 1e-5, D ** -0.5, w_out_frag=wofrag, bias_out=bo,
+                         residual=x if residual else None)
+
+
+def two_launch_out(x, w, gamma, beta, pe, b, tokens, wo, bo, wfrag=None, residual=True):
+    """What the fused output stage replaces: ca_tattn_fused, then the to_out GEMM (+ bias + residual)."""
+    o = fused(x, w, gamma, beta, pe, b, tokens, wfrag)
+    return K.gemm(o, wo, bias=bo, residual=x if residual else None)
+
+
+def check_out():
+    from controlanimate_amd.layers import frag_order_wout
+    bad = 0
+    for dt in (torch.float16, torch.bfloat16):
+        for (b, tokens, lda, res) in [(2, 4096, 320, True), (1, 1024, 320, True), (3, 1032, 640, True), (2, 2048, 320, False)]:
+            x, w, gamma, beta, pe = make(b, tokens, dt, lda=lda)
+            wo, bo = make_out(dt)
+            ref = reference(x, w, gamma, beta, pe, b, tokens) @ wo.float().t() + bo[None, :] + (x.float() if res else 0.0)
+            wol = torch.empty(102400, device=dev, dtype=dt)
+            K.check(K.lib().ca_pack_w_out(wo.data_ptr(), 320, 320, wol.data_ptr(), K._stream()), "ca_pack_w_out")
+            same_pack = torch.equal(wol, frag_order_wout(wo.float()).to(dt))
+            outs = [fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, wofrag=wol, residual=res) for _ in range(3)]
+            if outs[0] is None:
+                print(f"out {str(dt)[6:]:9s} b={b} tokens={tokens}: not taken by the library   <<<<<< FAIL")
+                bad += 1
+                continue
+            old = two_launch_out(x, w, gamma, beta, pe, b, tokens, wo, bo, residual=res)
+            rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
+            rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+            diff = int((outs[0] != old).sum())
+            det = all(torch.equal(outs[0], o) for o in outs[1:])
+            tol = 2e-3 if dt == torch.float16 else 1.2e-2
+            ok = rel < tol and rel < 1.5 * rel_old + 1e-4 and det and same_pack and bool(torch.isfinite(outs[0].float()).all())
+            bad += not ok
+            print(f"out {str(dt)[6:]:9s} b={b} tokens={tokens:5d} lda={lda} residual={res}: rel {rel:.2e} (two launches {rel_old:.2e}; {diff} of {old.numel()} elements "
+                  f"differ from them) deterministic={det} pack={same_pack}{'' if ok else '   <<<<<< FAIL'}", flush=True)
+    return bad
+
+
 def check():
     bad = 0
     for dt in (torch.float16, torch.bfloat16):
@@ -127,15 +182,20 @@ def timing():
                 qkv = K.gemm(x, wf, bias=bias, ln=(K.RowStats(x, 1e-5), cs), rowbias=rb, rows_per_group=tokens)
                 return K.attention_temporal(qkv, b, FR, tokens, HEADS)
             row = []
+            wo, bo = make_out(dt)
+            from controlanimate_amd.layers import frag_order_wout
+            wol = frag_order_wout(wo.float()).to(dt)
             for _ in range(2):
                 row.append(("fused", timeit(lambda: K.tattn_fused(x, wl, gamma, bp, b, FR, tokens, HEADS, 1e-5, D ** -0.5))))
                 row.append(("gemm+attn", timeit(old)))
+                row.append(("fused+out", timeit(lambda: K.tattn_fused(x, wl, gamma, bp, b, FR, tokens, HEADS, 1e-5, D ** -0.5, w_out_frag=wol, bias_out=bo, residual=x))))
+                row.append(("fused, to_out", timeit(lambda: K.gemm(K.tattn_fused(x, wl, gamma, bp, b, FR, tokens, HEADS, 1e-5, D ** -0.5), wo, bias=bo, residual=x))))
             print(f"time {str(dt)[6:]:9s} rows {b * FR * tokens:7d}: " + "  ".join(f"{n} {us:7.1f} us" for n, us in row), flush=True)
 
 
 if __name__ == "__main__":
     rc = 0
     if "--time-only" not in sys.argv:
-        rc = check()
+        rc = check() + check_out()
     timing()
     sys.exit(1 if rc else 0)

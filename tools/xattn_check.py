@@ -57,6 +57,56 @@ def fused(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, packed=None):
     return K.xattn_fused(x, packed[0], bias, packed[1], images, tokens, fpk, kvb, nk, 1e-5)
 
 
+def make_out(dt, seed=11):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    wo = (torch.randn(CH, CH, generator=g) * CH ** -0.5 * 1.5).to(dev).to(dt)
+    bo = (torch.randn(CH, generator=g) * 0.1).to(dev)
+    return wo, bo
+
+
+def fused_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, bo, packed=None, wofrag=None, residual=True):
+    """ABI v12: attention + output projection + bias + residual (the block's own input) in one launch."""
+    from controlanimate_amd.layers import frag_order_wout
+    wf, cs, bias = operands(x, wq, gamma, beta, x.dtype)
+    if packed is None:
+        packed = (frag_order_xattn(wf.float()).to(x.dtype), K.xattn_pack_kv(kv, kvb, L, nk, D ** -0.5))
+    if wofrag is None:
+        wofrag = frag_order_wout(wo.float()).to(x.dtype)
+    return K.xattn_fused(x, packed[0], bias, packed[1], images, tokens, fpk, kvb, nk, 1e-5, w_out_frag=wofrag, bias_out=bo,
+                         residual=x if residual else None)
+
+
+def two_launch_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, bo, packed=None, residual=True):
+    o = fused(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, packed)
+    return K.gemm(o, wo, bias=bo, residual=x if residual else None)
+
+
+def check_out():
+    bad = 0
+    for dt in (torch.float16, torch.bfloat16):
+        for (images, tokens, L, nk, fpk, kvb, lda, res) in [(32, 4096, 77, 77, 16, 2, 320, True), (8, 2048, 77, 77, 4, 2, 320, True),
+                                                            (6, 3072, 81, 77, 2, 3, 640, True), (16, 1024, 70, 70, 8, 2, 320, False)]:
+            x, wq, gamma, beta, kv = make(images, tokens, L, kvb, dt, lda=lda)
+            wo, bo = make_out(dt)
+            ref = reference(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, dt) @ wo.float().t() + bo[None, :] + (x.float() if res else 0.0)
+            outs = [fused_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, bo, residual=res) for _ in range(3)]
+            if outs[0] is None:
+                print(f"out {str(dt)[6:]:9s} images={images} tokens={tokens}: not taken by the library   <<<<<< FAIL")
+                bad += 1
+                continue
+            old = two_launch_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, bo, residual=res)
+            rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
+            rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+            diff = int((outs[0] != old).sum())
+            det = all(torch.equal(outs[0], o) for o in outs[1:])
+            tol = 2e-3 if dt == torch.float16 else 1.2e-2
+            ok = rel < tol and rel < 1.5 * rel_old + 1e-4 and det and bool(torch.isfinite(outs[0].float()).all())
+            bad += not ok
+            print(f"out {str(dt)[6:]:9s} images={images} tokens={tokens:5d} L={L} lda={lda} residual={res}: rel {rel:.2e} (two launches {rel_old:.2e}; {diff} of "
+                  f"{old.numel()} elements differ from them) deterministic={det}{'' if ok else '   <<<<<< FAIL'}", flush=True)
+    return bad
+
+
 def check():
     bad = 0
     for dt in (torch.float16, torch.bfloat16):
@@ -117,15 +167,20 @@ def timing():
                 q = K.gemm(x, wf, bias=bias, ln=(K.RowStats(x, 1e-5), cs))
                 return K.attention_cross(q, kv, images, tokens, HEADS, nk, L, fpk, kv_mod=kvb)
             row = []
+            from controlanimate_amd.layers import frag_order_wout
+            wo, bo = make_out(dt)
+            wol = frag_order_wout(wo.float()).to(dt)
             for _ in range(2):
                 row.append(("fused", timeit(lambda: K.xattn_fused(x, packed[0], bias, packed[1], images, tokens, fpk, kvb, nk, 1e-5))))
                 row.append(("gemm+attn", timeit(old)))
+                row.append(("fused+out", timeit(lambda: K.xattn_fused(x, packed[0], bias, packed[1], images, tokens, fpk, kvb, nk, 1e-5, w_out_frag=wol, bias_out=bo, residual=x))))
+                row.append(("fused, to_out", timeit(lambda: K.gemm(K.xattn_fused(x, packed[0], bias, packed[1], images, tokens, fpk, kvb, nk, 1e-5), wo, bias=bo, residual=x))))
             print(f"time {str(dt)[6:]:9s} rows {images * tokens:7d}: " + "  ".join(f"{n} {us:7.1f} us" for n, us in row), flush=True)
 
 
 if __name__ == "__main__":
     rc = 0
     if "--time-only" not in sys.argv:
-        rc = check()
+        rc = check() + check_out()
     timing()
     sys.exit(1 if rc else 0)
