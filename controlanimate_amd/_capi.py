@@ -47,6 +47,7 @@ class FfArgs(C.Structure):
         ("w2_frag", C.c_void_p), ("bias2", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
         ("lda", C.c_int64), ("ldc", C.c_int64), ("ld_res", C.c_int64),
         ("m", C.c_int32), ("c", C.c_int32), ("inner", C.c_int32), ("ln_eps", C.c_float), ("dtype", C.c_int32),
+        ("w_out_frag", C.c_void_p), ("bias_out", C.c_void_p), ("residual_out", C.c_void_p), ("ld_res_out", C.c_int64),  # ABI v12
     ]
 
 

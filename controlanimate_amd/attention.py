@@ -19,7 +19,7 @@ from torch import nn
 
 from . import kernels as K
 from .attention_processor import Attention, AttnProcessor2_0
-from .context import ExecCtx
+from .context import ExecCtx, dispatch
 from .layers import HipConv1x1, HipGroupNorm, HipLayerNorm, HipLinear, LnFold, WeightArena, _f32, geglu_interleave, ln_fold_enabled
 
 
@@ -62,6 +62,16 @@ class FeedForward(nn.Module):
         if self.fold is not None and self.fold.w.frag is not None and (out.out_features, out.in_features) == (320, 1280):
             from .layers import frag_order2
             self.w2f = arena.add((320, 1280), dtype, lambda: frag_order2(out.weight.detach().float()))
+
+    def run_with_proj_out(self, x: torch.Tensor, residual: Optional[torch.Tensor], proj_frag, proj_bias, proj_residual) -> Optional[torch.Tensor]:
+        """The feed-forward AND the transformer's proj_out + bias + residual behind it in one launch (ca_ff_fused with w_out_frag,
+        ABI v12) -- or None where the one-launch feed-forward does not apply (the caller runs the feed-forward, then proj_out)."""
+        fold = getattr(self, "fold", None)
+        if fold is None or getattr(self, "w2f", None) is None or proj_frag is None or not dispatch.attn_out_fused:
+            return None
+        return K.ff_fused(x, fold.w.frag[0].t, fold.b.t, fold.cs.t, self.w2f.t, None if self.net[2].b is None else self.net[2].b.t,
+                          fold.eps, residual=residual, w_out_frag=proj_frag.t, bias_out=None if proj_bias is None else proj_bias.t,
+                          residual_out=proj_residual)
 
     def run(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, sums=None) -> torch.Tensor:
         """With a folded LayerNorm `x` is the UN-normalised input (`sums`: row sums its producer left, K.row_sums_of)."""
@@ -116,9 +126,10 @@ class BasicTransformerBlock(nn.Module):
         self.ff.pack(arena, dtype, fold_ln=self.norm3)
         self.norm3.pack(arena, dtype)
 
-    def forward(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
-        """x: [images, tokens, C]."""
-        return self.forward_rest(self.forward_self(x), ctx)
+    def forward(self, x: torch.Tensor, ctx: ExecCtx, proj_out=None) -> torch.Tensor:
+        """x: [images, tokens, C].  proj_out = (fragment-ordered weight, bias, residual rows) of the transformer this block ends:
+        applied in the feed-forward's launch where possible -- the result then carries `_proj_out_done`."""
+        return self.forward_rest(self.forward_self(x), ctx, proj_out=proj_out)
 
     def forward_self(self, x: torch.Tensor) -> torch.Tensor:
         """norm1 + self-attention + residual: the part that does not see the prompt (UNet3DConditionModel.forward_nhwc
@@ -133,7 +144,7 @@ class BasicTransformerBlock(nn.Module):
             x = self.attn1(self.norm1.run(x.view(B * N, C)).view(B, N, C), residual=x, row_sums=next_folded)
         return x
 
-    def forward_rest(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
+    def forward_rest(self, x: torch.Tensor, ctx: ExecCtx, proj_out=None) -> torch.Tensor:
         """norm2 + cross-attention, norm3 + feed-forward (with their residuals)."""
         B, N, C = x.shape
         if self.attn2 is not None:
@@ -146,6 +157,12 @@ class BasicTransformerBlock(nn.Module):
         x2 = x.view(B * N, C)
         if self.ff.fold is None:
             return self.ff.run(self.norm3.run(x2), residual=x2).view(B, N, C)
+        if proj_out is not None and K.row_sums_of(x) is None:
+            y = self.ff.run_with_proj_out(x2, x2, *proj_out)
+            if y is not None:
+                y = y.view(B, N, C)
+                y._proj_out_done = True
+                return y
         return self.ff.run(x2, residual=x2, sums=K.row_sums_of(x)).view(B, N, C)
 
 
@@ -171,6 +188,12 @@ class Transformer3DModel(nn.Module):
         for b in self.transformer_blocks:
             b.pack(arena, dtype)
         self.proj_out.pack(arena, dtype)
+        # proj_out once more in the fragment order of the output stage behind the last block's feed-forward (ca_ff_fused, ABI v12)
+        self.proj_out_frag = None
+        po = self.proj_out
+        if tuple(po.weight.shape[:2]) == (320, 320) and getattr(self.transformer_blocks[-1].ff, "w2f", None) is not None:
+            from .layers import frag_order_wout
+            self.proj_out_frag = arena.add((102400,), dtype, lambda: frag_order_wout(_f32(po.weight).reshape(320, 320)))
 
     def forward(self, x: torch.Tensor, ctx: ExecCtx, shared_half: bool = False) -> torch.Tensor:
         """shared_half: `x` holds ONE of the two identical halves of a classifier-free-guidance batch (ctx describes the
@@ -182,11 +205,18 @@ class Transformer3DModel(nn.Module):
         y = self.norm.run(x)  # always per image (reference rearranges to (b f) first, attention.py:124)
         y0 = self.proj_in.run(y.view(rows, c), row_sums=self.transformer_blocks[0].attn1.fold is not None)
         y = K.carry_row_sums(y0.view(images, h * w, -1), y0)
+        nblk = len(self.transformer_blocks)
+        pfrag = getattr(self, "proj_out_frag", None)
+
+        def proj(k, x_rows):  # the last block takes proj_out + bias + residual into its feed-forward's launch where it can
+            return (pfrag, self.proj_out.b, x_rows) if (k == nblk - 1 and pfrag is not None) else None
         if shared_half:
             y = self.transformer_blocks[0].forward_self(y)
             y, x = K.repeat_batch(y), K.repeat_batch(x)  # (= torch.cat([t, t]), one read each)
             images, rows = 2 * images, 2 * rows
-            y = self.transformer_blocks[0].forward_rest(y, ctx)
-        for blk in (self.transformer_blocks[1:] if shared_half else self.transformer_blocks):
-            y = blk(y, ctx)
+            y = self.transformer_blocks[0].forward_rest(y, ctx, proj_out=proj(0, x.view(rows, c)))
+        for k in range(1 if shared_half else 0, nblk):
+            y = self.transformer_blocks[k](y, ctx, proj_out=proj(k, x.view(rows, c)))
+        if getattr(y, "_proj_out_done", False):
+            return y.view(images, h, w, c)
         return self.proj_out.run(y.view(rows, -1), residual=x.view(rows, c)).view(images, h, w, c)

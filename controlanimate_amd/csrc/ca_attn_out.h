@@ -28,6 +28,14 @@ __global__ __launch_bounds__(256) void k_pack_w_out(const u16* __restrict__ w, u
   st16(dst + (int64_t)idx * 8, ld16(w + (int64_t)row * 320 + kq * 32 + (L >> 4) * 8));
 }
 
+// 8-byte LDS store that the compiler does not fence: a compiler-visible LDS access narrower than 16 bytes into a region an LDS-DMA may
+// fill is preceded by s_waitcnt vmcnt(0) -- here that would drain the stage's prefetch.  The caller retires it with
+// s_waitcnt lgkmcnt(0) in front of its barrier.
+__device__ __forceinline__ void ca_lds_store8(unsigned char* p, u32x2 v) {
+  const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)p;
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
 struct AttnOutParams {
   const u16* wof;      // fragment-ordered Wout, or NULL: no output stage
   const float* bias;   // [320] or NULL

@@ -60,6 +60,7 @@ struct FfParams {
   int m;
   float ln_eps;
   unsigned x_bytes, y_bytes, res_bytes;
+  AttnOutParams out;  // ABI v12: the transformer's proj_out + bias + residual behind the feed-forward (ca_attn_out.h), or wof = NULL
 };
 
 #ifdef CA_EXPERIMENTS
@@ -75,7 +76,7 @@ __device__ unsigned long long ca_ff_stamps[2][256];
 #define CA_FF_STAMP(TAG)
 #endif
 
-template <int DT>
+template <int DT, bool OUT>
 __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
 #ifdef CA_EXPERIMENTS
   int stamp_i = 0;
@@ -104,6 +105,11 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
   const __amdgpu_buffer_rsrc_t rs_b2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias2 ? (const void*)p.bias2 : (const void*)p.w2f), 0, p.bias2 ? 320u * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.y), 0, p.res ? p.res_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+  // the output stage (proj_out of the transformer the feed-forward ends: y_out = y Wout^T + b_out + residual_out)
+  constexpr bool with_out = OUT;  // (a template parameter: the plain instantiation keeps its register allocation)
+  const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc((void*)(with_out ? (const void*)p.out.wof : (const void*)p.w2f), 0, with_out ? (unsigned)CA_WOUT_ELEMS * 2u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out.bias ? (const void*)p.out.bias : (const void*)p.w2f), 0, p.out.bias ? 320u * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ro = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out.res ? (const void*)p.out.res : (const void*)p.w2f), 0, p.out.res ? p.out.res_bytes : 0u, 0x00020000);
 
   // A-tile fragment addresses (ca_gemm_ar.h): four bases, every fragment = base + a 16-bit immediate
   const int f_sw = (l15 >> 1) & 7;
@@ -234,7 +240,8 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         CA_FF_STAMP(2)
-        if (r + 1 == ROUNDS && tile + (int)gridDim.x < tiles_m) x_tile_dma(tile + gridDim.x);  // (every producer's reads of the x tile are over)
+        // (every producer's reads of the x tile are over; with the output stage the buffer first holds the y tile: requested behind it)
+        if (r + 1 == ROUNDS && !with_out && tile + (int)gridDim.x < tiles_m) x_tile_dma(tile + gridDim.x);
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int l15 = lane_e & 15, g = lane_e >> 4;
@@ -273,7 +280,21 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
       }
       // the drain round (consumers: stage 2 of round 9) and the consumers' epilogue: two more barriers
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_barrier();
+      if (with_out) {  // rows 0..63 of the y tile the consumers leave in the x buffer: this wave's 64 x 80 patch of y Wout^T
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const unsigned row_base = (unsigned)(m0 + (lane_e & 15));
+        AttnOutRegs R;
+        attn_out_prefetch<DT>(R, p.out, rs_wo, rs_ro, wid, lane_e, row_base, 16u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // the y tile is complete
+        attn_out_run<DT>(R, smem, fa_b, p.out, rs_wo, rs_bo, rs_y, wid, lane_e, row_base, 16u, (unsigned)p.ldc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave has read the y tile: the next x tile may land
+        if (tile + (int)gridDim.x < tiles_m) x_tile_dma(tile + gridDim.x);
+      } else {
+        __builtin_amdgcn_s_barrier();
+      }
     } else {
       // ================================================================ consumers: y += H . W2^T
       f32x4 yacc[TM][5];
@@ -362,15 +383,37 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (with_out) {
+        // y (rounded to the activation type, as the two-launch path stores it) -> the x buffer in the tile layout, then rows 64..127
+        // of the output stage; the producers run rows 0..63
+        const unsigned row_base = (unsigned)(m0 + 64 + l15);
+        const int fs = (l15 >> 1) & 7;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = m0 + i * 16 + l15;
-        const unsigned ro = m < p.m ? (unsigned)m * (unsigned)p.ldc * 2u + (unsigned)n0 * 2u : OOB_V;
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][0], w[i][1], w[i][2], w[i][3]}, rs_y, ro + (unsigned)(8 * g) * 2u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][4], w[i][5], w[i][6], w[i][7]}, rs_y, ro + (unsigned)(32 + 8 * g) * 2u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64((u32x2){w[i][8], w[i][9]}, rs_y, ro + (unsigned)(64 + 4 * g) * 2u, 0, 0);
+        for (int i = 0; i < TM; ++i) {
+          unsigned char* rowp = smem + (i * 16 + l15) * ROWB;
+          const int c0 = n0 + 8 * g, c1 = n0 + 32 + 8 * g, c2 = n0 + 64 + 4 * g;
+          st16(rowp + (((c0 >> 3) ^ fs) << 4), (u32x4){w[i][0], w[i][1], w[i][2], w[i][3]});
+          st16(rowp + (((c1 >> 3) ^ fs) << 4), (u32x4){w[i][4], w[i][5], w[i][6], w[i][7]});
+          ca_lds_store8(rowp + (((c2 >> 3) ^ fs) << 4) + (c2 & 7) * 2, (u32x2){w[i][8], w[i][9]});
+        }
+        AttnOutRegs R;
+        attn_out_prefetch<DT>(R, p.out, rs_wo, rs_ro, wid, lane_e, row_base, 16u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // the y tile is complete (matches the producers' barrier)
+        attn_out_run<DT>(R, smem, fa_b, p.out, rs_wo, rs_bo, rs_y, wid, lane_e, row_base, 16u, (unsigned)p.ldc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave has read the y tile
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = m0 + i * 16 + l15;
+          const unsigned ro = m < p.m ? (unsigned)m * (unsigned)p.ldc * 2u + (unsigned)n0 * 2u : OOB_V;
+          __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][0], w[i][1], w[i][2], w[i][3]}, rs_y, ro + (unsigned)(8 * g) * 2u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][4], w[i][5], w[i][6], w[i][7]}, rs_y, ro + (unsigned)(32 + 8 * g) * 2u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64((u32x2){w[i][8], w[i][9]}, rs_y, ro + (unsigned)(64 + 4 * g) * 2u, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();  // (matches the producers' last barrier: the tile is done)
       }
-      __builtin_amdgcn_s_barrier();  // (matches the producers' last barrier: the tile is done)
     }
   }
 }

@@ -20,8 +20,8 @@ int ar_cu_count() {
 namespace {
 using namespace ca_gemm_detail;
 #include "ca_gemm_ar.h"
-#include "ca_ff_fused.h"
 #include "ca_attn_out.h"
+#include "ca_ff_fused.h"
 #include "ca_tattn_fused.h"
 #include "ca_xattn_fused.h"
 
@@ -66,6 +66,14 @@ extern "C" int ca_pack_w2_frag(const void* w, int32_t n, int32_t k, void* dst, v
   return CA_OK;
 }
 
+// the optional output stage of the one-launch attentions (ABI v12): 1 = absent or acceptable
+static int attn_out_args_ok(const void* w_out_frag, const float* bias_out, const void* residual, int64_t ld_res, int64_t rows) {
+  if (!w_out_frag) return (bias_out || residual) ? 0 : 1;  // bias / residual belong to the projection
+  if ((((uintptr_t)w_out_frag | (uintptr_t)bias_out | (uintptr_t)residual) & 15) != 0) return 0;
+  if (residual && (ld_res % 8 || ld_res < 320 || ((rows - 1) * ld_res + 320) * 2 >= 0x7FFFFF00ll)) return 0;
+  return 1;
+}
+
 extern "C" int ca_ff_fused_supported(const ca_ff_args* a) {
   if (!a || !a->x || !a->w1_frag || !a->bias1 || !a->colsum1 || !a->w2_frag || !a->y) return 0;
   if (a->c != 320 || a->inner != 1280 || a->m < 16384) return 0;
@@ -79,6 +87,8 @@ extern "C" int ca_ff_fused_supported(const ca_ff_args* a) {
   if (((int64_t)(a->m - 1) * a->lda + 320) * 2 >= lim || ((int64_t)(a->m - 1) * a->ldc + 320) * 2 >= lim) return 0;
   if (a->residual && ((int64_t)(a->m - 1) * a->ld_res + 320) * 2 >= lim) return 0;
   if (!a->ln_stats && !(a->ln_eps > 0.f)) return 0;
+  if (!attn_out_args_ok(a->w_out_frag, a->bias_out, a->residual_out, a->ld_res_out, a->m)) return 0;
+  if (a->w_out_frag && a->m % 128) return 0;  // the output stage works on whole row tiles
   return 1;
 }
 
@@ -102,10 +112,22 @@ extern "C" int ca_ff_fused(const ca_ff_args* a, void* stream) {
   p.x_bytes = (unsigned)(((int64_t)(a->m - 1) * a->lda + 320) * 2);
   p.y_bytes = (unsigned)(((int64_t)(a->m - 1) * a->ldc + 320) * 2);
   p.res_bytes = a->residual ? (unsigned)(((int64_t)(a->m - 1) * a->ld_res + 320) * 2) : 0u;
+  if (a->w_out_frag) {
+    p.out.wof = (const u16*)a->w_out_frag;
+    p.out.bias = a->bias_out;
+    p.out.res = (const u16*)a->residual_out;
+    p.out.ld_res = (int)a->ld_res_out;
+    p.out.res_bytes = a->residual_out ? (unsigned)(((int64_t)(a->m - 1) * a->ld_res_out + 320) * 2) : 0u;
+  }
   const int tiles_m = (a->m + 127) / 128;
   const unsigned grid = (unsigned)(tiles_m < ar_cu_count() ? tiles_m : ar_cu_count());
-  if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_ff_fused<CA_BF16>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
-  else hipLaunchKernelGGL((k_ff_fused<CA_F16>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
+  if (a->w_out_frag) {
+    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_ff_fused<CA_BF16, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
+    else hipLaunchKernelGGL((k_ff_fused<CA_F16, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
+  } else {
+    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_ff_fused<CA_BF16, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
+    else hipLaunchKernelGGL((k_ff_fused<CA_F16, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tiles_m);
+  }
   CA_CHECK_LAUNCH("ca_ff_fused");
   return CA_OK;
 }
@@ -128,14 +150,6 @@ extern "C" int ca_pack_w_out(const void* w, int32_t n, int32_t k, void* dst, voi
   hipLaunchKernelGGL(k_pack_w_out, dim3((CA_WOUT_ELEMS / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u16*)w, (u16*)dst);
   CA_CHECK_LAUNCH("ca_pack_w_out");
   return CA_OK;
-}
-
-// the optional output stage of the one-launch attentions (ABI v12): 1 = absent or acceptable
-static int attn_out_args_ok(const void* w_out_frag, const float* bias_out, const void* residual, int64_t ld_res, int64_t rows) {
-  if (!w_out_frag) return (bias_out || residual) ? 0 : 1;  // bias / residual belong to the projection
-  if ((((uintptr_t)w_out_frag | (uintptr_t)bias_out | (uintptr_t)residual) & 15) != 0) return 0;
-  if (residual && (ld_res % 8 || ld_res < 320 || ((rows - 1) * ld_res + 320) * 2 >= 0x7FFFFF00ll)) return 0;
-  return 1;
 }
 
 extern "C" int ca_tattn_fused_supported(const ca_tattn_args* a) {

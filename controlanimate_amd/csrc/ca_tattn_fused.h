@@ -502,9 +502,10 @@ __global__ __launch_bounds__(512, 2) void k_tattn_out(TattnParams p, int tiles) 
         const int dv = 16 * j + 4 * ge;
         if (dv < HD) {
           const int col = wid * HD + dv;
-          *reinterpret_cast<u32x2*>(xb + (16 * i + l15e) * ROWB + (((col >> 3) ^ ((l15e >> 1) & 7)) << 4) + (col & 7) * 2) = op[i][j];
+          ca_lds_store8(xb + (16 * i + l15e) * ROWB + (((col >> 3) ^ ((l15e >> 1) & 7)) << 4) + (col & 7) * 2, op[i][j]);
         }
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // the o tile is complete
     attn_out_run<DT>(R, xb, fa_b, p.out, rs_wo, rs_bo, rs_o, wid, lane_e, row_base, 1u, (unsigned)p.ldo);
   }

@@ -148,24 +148,33 @@ def attach_w_frag(w: torch.Tensor, geglu: bool = False) -> torch.Tensor:
 
 def ff_fused(x: torch.Tensor, w1_frag: torch.Tensor, bias1: torch.Tensor, colsum1: torch.Tensor, w2_frag: torch.Tensor,
              bias2: Optional[torch.Tensor], ln_eps: float, residual: Optional[torch.Tensor] = None,
-             ln_stats: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+             ln_stats: Optional[torch.Tensor] = None, *, w_out_frag: Optional[torch.Tensor] = None, bias_out: Optional[torch.Tensor] = None,
+             residual_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """y = GEGLU(LN(x) W1^T + b1) W2^T + b2 + residual in one launch (ca_ff_fused, ABI v9: the 64x64-latent level's feed-forward,
-    C = 320) -- or None where the library does not take the arguments (the caller then runs the two GEMMs)."""
+    C = 320) -- or None where the library does not take the arguments (the caller then runs the two GEMMs).
+    With w_out_frag (layers.frag_order_wout of the transformer's proj_out.weight; ABI v12) the launch also applies that projection
+    and returns y Wout^T + bias_out + residual_out."""
     if not dispatch.ff_fused:
         return None
-    _req_cuda(x, w1_frag, bias1, colsum1, w2_frag, bias2, residual, ln_stats)
+    _req_cuda(x, w1_frag, bias1, colsum1, w2_frag, bias2, residual, ln_stats, w_out_frag, bias_out, residual_out)
     if x.dim() != 2 or x.stride(1) != 1 or (residual is not None and (residual.shape != x.shape or residual.stride(1) != 1 or residual.dtype != x.dtype)):
+        return None
+    if w_out_frag is None and (bias_out is not None or residual_out is not None):
+        return None
+    if residual_out is not None and (residual_out.shape != x.shape or residual_out.stride(1) != 1 or residual_out.dtype != x.dtype):
         return None
     m, c = x.shape
     inner = w2_frag.shape[1]
     y = torch.empty((m, c), device=x.device, dtype=x.dtype)
     args = FfArgs(x=_p(x), w1_frag=_p(w1_frag), bias1=_p(bias1), colsum1=_p(colsum1), ln_stats=_p(ln_stats), w2_frag=_p(w2_frag),
                   bias2=_p(bias2), residual=_p(residual), y=_p(y), lda=x.stride(0), ldc=y.stride(0),
-                  ld_res=residual.stride(0) if residual is not None else 0, m=m, c=c, inner=inner, ln_eps=float(ln_eps), dtype=dt_code(x.dtype))
+                  ld_res=residual.stride(0) if residual is not None else 0, m=m, c=c, inner=inner, ln_eps=float(ln_eps), dtype=dt_code(x.dtype),
+                  w_out_frag=_p(w_out_frag), bias_out=_p(bias_out), residual_out=_p(residual_out),
+                  ld_res_out=residual_out.stride(0) if residual_out is not None else 0)
     if not lib().ca_ff_fused_supported(C.byref(args)):
         return None
     if _plan_sink is not None:
-        _plan_sink.append("ff_fused128")
+        _plan_sink.append("ff_out128" if w_out_frag is not None else "ff_fused128")
     check(lib().ca_ff_fused(C.byref(args), _stream()), "ca_ff_fused")
     return y
 

@@ -109,8 +109,9 @@ class TemporalTransformerBlock(nn.Module):
         self.ff.pack(arena, dtype, fold_ln=self.ff_norm)
         self.ff_norm.pack(arena, dtype)
 
-    def forward(self, x: torch.Tensor, ctx: ExecCtx, tokens: int) -> torch.Tensor:
-        """x: [(b f n), C] rows."""
+    def forward(self, x: torch.Tensor, ctx: ExecCtx, tokens: int, proj_out=None) -> torch.Tensor:
+        """x: [(b f n), C] rows.  proj_out = (fragment-ordered weight, bias, residual rows) of the temporal transformer this block ends:
+        applied in the feed-forward's launch where possible (ca_ff_fused, ABI v12) -- the result then carries `_proj_out_done`."""
         rows, C = x.shape
         nblk = len(self.attention_blocks)
         for i, (attn, norm) in enumerate(zip(self.attention_blocks, self.norms)):
@@ -126,6 +127,11 @@ class TemporalTransformerBlock(nn.Module):
             x = K.carry_row_sums(o.view(rows, C), o)
         if self.ff.fold is None:
             return self.ff.run(self.ff_norm.run(x), residual=x)
+        if proj_out is not None and K.row_sums_of(x) is None:
+            y = self.ff.run_with_proj_out(x, x, *proj_out)
+            if y is not None:
+                y._proj_out_done = True
+                return y
         return self.ff.run(x, residual=x, sums=K.row_sums_of(x))
 
 
@@ -146,14 +152,24 @@ class TemporalTransformer3DModel(nn.Module):
         for b in self.transformer_blocks:
             b.pack(arena, dtype)
         self.proj_out.pack(arena, dtype)
+        # proj_out once more in the fragment order of the output stage behind the last block's feed-forward (ca_ff_fused, ABI v12)
+        self.proj_out_frag = None
+        po = self.proj_out
+        if tuple(po.weight.shape) == (320, 320) and getattr(self.transformer_blocks[-1].ff, "w2f", None) is not None:
+            from .layers import frag_order_wout
+            self.proj_out_frag = arena.add((102400,), dtype, lambda: frag_order_wout(_f32(po.weight)))
 
     def forward(self, x: torch.Tensor, ctx: ExecCtx) -> torch.Tensor:
         images, h, w, c = x.shape
         rows = images * h * w
         y = self.norm.run(x)  # per image ('(b f) c h w', motion_module.py:139-144)
         y = self.proj_in.run(y.view(rows, c), row_sums=self.transformer_blocks[0].attention_blocks[0].fold is not None)
-        for blk in self.transformer_blocks:
-            y = blk(y, ctx, h * w)
+        pfrag = getattr(self, "proj_out_frag", None)
+        last = len(self.transformer_blocks) - 1
+        for k, blk in enumerate(self.transformer_blocks):
+            y = blk(y, ctx, h * w, proj_out=(pfrag, self.proj_out.b, x.view(rows, c)) if (k == last and pfrag is not None) else None)
+        if getattr(y, "_proj_out_done", False):
+            return y.view(images, h, w, c)
         return self.proj_out.run(y, residual=x.view(rows, c)).view(images, h, w, c)
 
 

@@ -160,6 +160,15 @@ typedef struct ca_ff_args {
   int32_t m, c, inner;
   float ln_eps;
   int32_t dtype;
+  /* ABI v12: the transformer's output projection behind its last feed-forward, in the same launch
+   * (animatediff/models/attention.py:163-175 `proj_out(hidden) + residual`; motion_module.py:158-163):  `y` then receives
+   *   y_out = (feed-forward output) Wout^T + bias_out + residual_out.
+   * w_out_frag: CA_ATTN_WOUT_FRAG_ELEMS elements written by ca_pack_w_out(proj_out.weight [c, c]); NULL = no output stage (as ABI v9).
+   * Needs m % 128 == 0.  bias_out [c] fp32 or NULL; residual_out rows at stride ld_res_out (the transformer's input) or NULL. */
+  const void* w_out_frag;
+  const float* bias_out;
+  const void* residual_out;
+  int64_t ld_res_out;
 } ca_ff_args;
 int ca_ff_fused(const ca_ff_args* args, void* stream);
 int ca_ff_fused_supported(const ca_ff_args* args);

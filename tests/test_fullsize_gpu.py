@@ -118,7 +118,7 @@ def test_config2_full_size_eps_vs_oracle():
     eps_product = K.nhwc_to_ncfhw_f32(eps_static, 2, 4, f).cpu()
     pk = {k: plabels.count(k) for k in sorted(set(plabels))}
     print("kernel labels of the PRODUCT step:", pk)
-    for need in ("ar128x64", "ff_fused", "tattn_out", "xattn_out", "pq256x320", "attn_dma40", "attn_dma80", "attn_short", "wres160", "ps128x320"):
+    for need in ("ar128x64", "ff_out", "tattn_out", "xattn_out", "pq256x320", "attn_dma40", "attn_dma80", "attn_short", "wres160", "ps128x320"):
         assert any(k.startswith(need) for k in pk), f"the product step at config-2 size never ran `{need}`: {pk}"
     del graph, eps_static, eps_eager
     del unet, net, cn, down, mid, out

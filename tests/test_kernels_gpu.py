@@ -869,3 +869,35 @@ def test_xattn_fused_with_output_projection_c320(dt, tol):
         old = X.two_launch_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, bo, residual=res)
         rel_old = ((old.float() - ref).norm() / ref.norm()).item()
         assert rel < tol and rel < 1.5 * rel_old + 1e-4, (rel, rel_old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ff_fused_with_proj_out_c320(dtype):
+    """ca_ff_fused with w_out_frag (ABI v12): the feed-forward, the transformer's proj_out, its bias and the transformer's residual in one
+    launch (animatediff/models/attention.py:163-175, motion_module.py:158-163) -- against fp32 torch and the two launches it replaces."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ff_check
+    k = _k()
+    tol = 2e-3 if dtype == torch.float16 else 1.2e-2
+    for (m, lda, res, with_res_out) in ((16384, 320, True, True), (32768, 640, True, True), (16384, 320, False, False)):
+        d = ff_check.make(m, dtype, lda=lda)
+        wo, bo = ff_check.make_out(dtype)
+        res_out = rnd(m, 320, dtype=dtype, seed=31).to(DEV) if with_res_out else None
+        k._plan_sink = labels = []
+        try:
+            outs = [ff_check.fused_out(d, wo, bo, res_out, res) for _ in range(2)]
+        finally:
+            k._plan_sink = None
+        assert outs[0] is not None and labels == ["ff_out128", "ff_out128"]
+        ref = ff_check.reference(d, res) @ wo.float().t() + bo[None, :] + (res_out.float() if with_res_out else 0.0)
+        two = ff_check.two_launch_out(d, wo, bo, res_out, res)
+        rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
+        rel_two = ((two.float() - ref).norm() / ref.norm()).item()
+        assert torch.isfinite(outs[0].float()).all() and rel < tol and rel < 1.5 * rel_two + 1e-4, (m, rel, rel_two)
+        assert torch.equal(outs[0], outs[1])
+    # the output stage works on whole row tiles: a ragged M is declined (the caller runs the feed-forward, then proj_out)
+    d = ff_check.make(16384 + 72, dtype)
+    wo, bo = ff_check.make_out(dtype)
+    assert ff_check.fused_out(d, wo, bo, None) is None

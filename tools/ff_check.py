@@ -51,6 +51,27 @@ def reference(d, residual=True):
     return y + x if residual else y
 
 
+def make_out(dt, seed=21):
+    """The transformer's proj_out behind the feed-forward: weight [320, 320], bias [320], and the transformer's input as residual."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    wo = (torch.randn(320, 320, generator=g) * 320 ** -0.5 * 1.5).to("cuda").to(dt)
+    bo = (torch.randn(320, generator=g) * 0.1).to("cuda")
+    return wo, bo
+
+
+def fused_out(d, wo, bo, res_out, residual=True, wofrag=None):
+    """ABI v12: feed-forward + proj_out + bias + residual_out in one launch."""
+    from controlanimate_amd.layers import frag_order_wout
+    if wofrag is None:
+        wofrag = frag_order_wout(wo.float()).to(wo.dtype)
+    return K.ff_fused(d["x"], d["w1f"], d["b1"], d["cs"], d["w2f"], d["b2"], 1e-5, residual=d["x"] if residual else None,
+                      w_out_frag=wofrag, bias_out=bo, residual_out=res_out)
+
+
+def two_launch_out(d, wo, bo, res_out, residual=True):
+    return K.gemm(fused(d, residual), wo, bias=bo, residual=res_out)
+
+
 def check():
     bad = 0
     for dt in (torch.float16, torch.bfloat16):
@@ -75,7 +96,13 @@ def check():
 
 def timing():
     d = make(131072, torch.float16)
-    for name, fn in (("fused", lambda: fused(d)), ("two GEMMs (ar + pq)", lambda: two_gemms(d)), ("fused", lambda: fused(d)), ("two GEMMs (ar + pq)", lambda: two_gemms(d))):
+    wo, bo = make_out(torch.float16)
+    from controlanimate_amd.layers import frag_order_wout
+    wol = frag_order_wout(wo.float()).to(wo.dtype)
+    res_out = torch.randn(131072, 320, device="cuda").half()
+    for name, fn in (("fused", lambda: fused(d)), ("two GEMMs (ar + pq)", lambda: two_gemms(d)), ("fused", lambda: fused(d)), ("two GEMMs (ar + pq)", lambda: two_gemms(d)),
+                     ("fused + proj_out", lambda: fused_out(d, wo, bo, res_out, wofrag=wol)), ("fused, proj_out", lambda: two_launch_out(d, wo, bo, res_out)),
+                     ("fused + proj_out", lambda: fused_out(d, wo, bo, res_out, wofrag=wol)), ("fused, proj_out", lambda: two_launch_out(d, wo, bo, res_out))):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
