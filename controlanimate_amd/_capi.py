@@ -91,6 +91,7 @@ class ConvArgs(C.Structure):
         ("alpha", C.c_float), ("post_scale", C.c_float),
         ("act", C.c_int32), ("out_f32", C.c_int32), ("dtype", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("pad_asym", C.c_int32),
+        ("w_wino", C.c_void_p),  # ABI v12
     ]
 
 
@@ -155,6 +156,7 @@ SYMBOLS = {
     "ca_gemm_plan_name": (C.c_int, [C.POINTER(GemmArgs), C.c_char_p, C.c_int32]),
     "ca_conv3x3_plan_name": (C.c_int, [C.POINTER(ConvArgs), C.c_char_p, C.c_int32]),
     "ca_conv3x3": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "ca_pack_w_wino": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ca_conv3x3_workspace_bytes": (C.c_int64, [C.POINTER(ConvArgs)]),
     "ca_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_float, C.c_int32, C.c_void_p]),
     "ca_groupnorm_partials_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -24,6 +24,7 @@
 
 namespace {
 using namespace ca_gemm_detail;
+#include "ca_conv_wino.h"
 
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
 __global__ __launch_bounds__(256) void k_gemm(GemmKParams p) {
@@ -951,8 +952,27 @@ extern "C" int ca_gemm_wants_finished_stats(const ca_gemm_args* a) {
   return plan_gemm(p, 0).kind == PK_PQ ? 1 : 0;
 }
 
+// The Winograd route of ca_conv3x3 (ca_conv_wino.h): 0 = not taken, else the workspace it needs (V [16][T][cin] + M [16][T][cout]).
+static int64_t wino_workspace_bytes(const ca_conv_args* a) {
+  if (!a || !a->w_wino || a->dtype != CA_F16 || a->stride != 1 || a->upsample || a->pad_asym || a->out_f32) return 0;
+  if (a->images <= 0 || a->hin < 2 || a->win < 2 || (a->hin & 1) || (a->win & 1)) return 0;
+  const int kc = a->cin1 + a->cin2;
+  if (kc < 1280 || kc % BK != 0 || a->cin1 % 8 != 0 || a->cin2 % 8 != 0 || a->cout % 320 != 0) return 0;
+  const int64_t tiles = (int64_t)a->images * (a->hin / 2) * (a->win / 2);
+  // whole 256-row tiles per transformed GEMM, and the small-latent levels only (16x16 and 8x8 latents at 32 images): above that the
+  // direct form fills the chip with 256 x 320 tiles and the 4 x larger V / M tensors cost more than the saved MFMAs
+  static const int max_tiles = CA_KNOB("CA_WINO_MAX_TILES", 4096);
+  if (tiles % 256 != 0 || tiles > max_tiles) return 0;
+  if (16 * tiles * (int64_t)(kc > a->cout ? kc : a->cout) * 2 >= 0x7FFFFF00ll) return 0;  // 32-bit byte offsets in the GEMM
+  return 16 * tiles * (int64_t)(kc + a->cout) * 2;
+}
+
 extern "C" int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* a) {
   if (!a || a->images <= 0 || a->hin <= 0 || a->win <= 0 || (a->stride != 1 && a->stride != 2)) return 0;
+  {
+    const int64_t wb = wino_workspace_bytes(a);
+    if (wb > 0) return wb;
+  }
   const int hl = a->hin << a->upsample, wl = a->win << a->upsample;
   const int pad = a->pad_asym ? 1 : 2;
   const int64_t m = (int64_t)a->images * ((hl + pad - 3) / a->stride + 1) * ((wl + pad - 3) / a->stride + 1);
@@ -1029,11 +1049,78 @@ static int conv_prepare(const ca_conv_args* a, GemmKParams& p) {
   return CA_OK;
 }
 
+static bool wino_taken(const ca_conv_args* a) {
+  const int64_t wb = wino_workspace_bytes(a);
+  return wb > 0 && a->workspace && a->workspace_bytes >= wb && (((uintptr_t)a->workspace | (uintptr_t)a->w_wino) & 15) == 0;
+}
+
+static int launch_conv_wino(const ca_conv_args* a, const GemmKParams& cp, hipStream_t st) {
+  const int kc = a->cin1 + a->cin2;
+  const int64_t tiles = (int64_t)a->images * (a->hin / 2) * (a->win / 2);
+  WinoParams w{};
+  w.x = (const u16*)a->x;
+  w.x2 = (const u16*)a->x2;
+  w.v = (u16*)a->workspace;
+  u16* mm = (u16*)a->workspace + 16 * tiles * kc;
+  w.mm = mm;
+  w.y = (u16*)a->y;
+  w.bias = a->bias;
+  w.rowbias = a->rowbias;
+  w.res = (const u16*)a->residual;
+  w.ld_res = a->ld_res;
+  w.ld_rowbias = a->ld_rowbias;
+  w.images = a->images, w.h = a->hin, w.w = a->win, w.c1 = a->cin1, w.c2 = a->cin2, w.cout = a->cout;
+  w.rows_per_group = cp.rows_per_group;
+  w.alpha = a->alpha, w.post = a->post_scale, w.act = a->act;
+  const int64_t in_threads = tiles * (kc / 8), out_threads = tiles * (a->cout / 8);
+  hipLaunchKernelGGL(k_wino_in, dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, st, w);
+  // the sixteen transformed GEMMs as ONE launch of the 256 x 320 kernel: A = V [16 T, kc], weights U_f for the rows of group f
+  GemmKParams q{};
+  q.a = w.v;
+  q.w = (const u16*)a->w_wino;
+  q.c = mm;
+  q.lda = kc;
+  q.ldc = a->cout;
+  q.a_bytes = desc_bytes(16 * tiles * kc);
+  q.w_bytes = desc_bytes((int64_t)16 * a->cout * kc);
+  q.m = (int)(16 * tiles);
+  q.n = a->cout;
+  q.c1 = kc;
+  q.taps = 1;
+  q.kc_tiles = kc / BK;
+  q.rows_per_group = 1;
+  q.alpha = 1.f, q.post = 1.f;
+  q.splits = 1;
+  q.w_group_rows = (int)tiles;
+  q.w_group_stride = (unsigned)((int64_t)a->cout * kc * 2);
+  const unsigned gemm_tiles = (unsigned)((q.m / 256) * (q.n / 320));
+  int rc = ca_launch_gemm_pp(q, CA_F16, 0, 323, gemm_tiles, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_wino_out<CA_F16>), dim3((unsigned)((out_threads + 255) / 256)), dim3(256), 0, st, w);
+  return CA_OK;
+}
+
+extern "C" int ca_pack_w_wino(const void* w, int32_t cout, int32_t cin, int32_t dtype, void* dst, void* stream) {
+  CA_REQUIRE(w && dst, "ca_pack_w_wino: null operand");
+  CA_REQUIRE(cout > 0 && cin > 0 && (dtype == CA_BF16 || dtype == CA_F16), "ca_pack_w_wino: cout=%d cin=%d dtype=%d", cout, cin, dtype);
+  const int64_t n = (int64_t)cout * cin;
+  if (dtype == CA_BF16) hipLaunchKernelGGL((k_pack_w_wino<CA_BF16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16*)w, (u16*)dst, cout, cin);
+  else hipLaunchKernelGGL((k_pack_w_wino<CA_F16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16*)w, (u16*)dst, cout, cin);
+  CA_CHECK_LAUNCH("ca_pack_w_wino");
+  return CA_OK;
+}
+
 extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
   GemmKParams p{};
   int rc = conv_prepare(a, p);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (wino_taken(a)) {
+    rc = launch_conv_wino(a, p, st);
+    if (rc) return rc;
+    CA_CHECK_LAUNCH("ca_conv3x3(winograd)");
+    return CA_OK;
+  }
   if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 1>(p, st);
   else launch_gemm<CA_F16, 1>(p, st);
   CA_CHECK_LAUNCH("ca_conv3x3");
@@ -1056,6 +1143,10 @@ extern "C" int ca_conv3x3_plan_name(const ca_conv_args* a, char* buf, int32_t le
   GemmKParams p{};
   int rc = conv_prepare(a, p);
   if (rc) return rc;
+  if (wino_taken(a)) {
+    snprintf(buf, (size_t)len, "wino_pq256x320");
+    return CA_OK;
+  }
   plan_label(plan_gemm(p, 1), buf, len);
   return CA_OK;
 }

@@ -41,6 +41,10 @@ struct GemmKParams {
   int ln_inline;  // ln_colsum without ln_stats: the kernel computes (mean, rstd) of the A rows itself (k_gemm_wres, k_gemm_ar)
   float ln_eps;
   const u16* wf;  // ABI v9: W once more in MFMA-fragment order (ca_pack_w_frag), or NULL: the activation-resident kernel reads it
+  // round 5: row-grouped weights (k_gemm_pq dense, EPI = 0): rows [g * w_group_rows, (g + 1) * w_group_rows) of A use the weight matrix
+  // at w + g * w_group_stride BYTES -- the sixteen independent GEMMs of a Winograd convolution as one launch (ca_conv_wino.h).  0 = off.
+  int w_group_rows;
+  unsigned w_group_stride;
 };
 
 constexpr int BK = 64;

@@ -141,15 +141,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
         a_v[i] = ok ? (unsigned)m * (unsigned)p.lda * 2u + (unsigned)((a_chunk0 ^ (4 * (i & 1))) * 16) : OOB_V;
       }
     }
+    // row-grouped weights (dense, EPI = 0 only: the Winograd convolutions' sixteen GEMMs in one launch): this row tile's weight matrix
+    unsigned wgrp = 0u;
+    if (MODE == 0 && EPI == 0 && p.w_group_rows > 0) wgrp = (unsigned)(m0 / p.w_group_rows) * p.w_group_stride;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = wid * 16 + i * 8 + r8;  // B0 local row r: quarter r >> 5, MFMA tile (r >> 4) & 1, fragment row r & 15
-      b0_v[i] = (unsigned)(n0 + (r >> 5) * 80 + ca_ps_col((r >> 4) & 1, r & 15, geglu)) * wld * 2u + (unsigned)((a_chunk0 ^ (4 * i)) * 16);
+      b0_v[i] = wgrp + (unsigned)(n0 + (r >> 5) * 80 + ca_ps_col((r >> 4) & 1, r & 15, geglu)) * wld * 2u + (unsigned)((a_chunk0 ^ (4 * i)) * 16);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int r1 = wid * 24 + i * 8 + r8;  // B1 local row r1: quarter r1 / 48, MFMA tile 2 + (r1 % 48) / 16, fragment row r1 & 15
-      b1_v[i] = (unsigned)(n0 + (r1 / 48) * 80 + ca_ps_col(2 + (r1 % 48) / 16, r1 & 15, geglu)) * wld * 2u + (unsigned)((b1_chunk0 ^ (4 * (i & 1))) * 16);
+      b1_v[i] = wgrp + (unsigned)(n0 + (r1 / 48) * 80 + ca_ps_col(2 + (r1 % 48) / 16, r1 & 15, geglu)) * wld * 2u + (unsigned)((b1_chunk0 ^ (4 * (i & 1))) * 16);
     }
     d_tap = 0;
     d_c0 = 0;

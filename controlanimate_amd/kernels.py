@@ -289,10 +289,12 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
             bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
             rows_per_group: int = 0, residual: Optional[torch.Tensor] = None, stride: int = 1,
             upsample: bool = False, alpha: float = 1.0, post_scale: float = 1.0, act: int = ACT_NONE,
-            out_f32: bool = False, pad_asym: bool = False) -> torch.Tensor:
+            out_f32: bool = False, pad_asym: bool = False, w_wino: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x: [images, H, W, Cin1] (+x2 [.., Cin2]); w: [Cout, 3, 3, Cin1+Cin2]; returns NHWC.
-    pad_asym: pad (0 before, 1 after) instead of 1/1 -- diffusers Downsample2D(padding=0)."""
-    _req_cuda(x, w, x2, bias, rowbias, residual)
+    pad_asym: pad (0 before, 1 after) instead of 1/1 -- diffusers Downsample2D(padding=0).
+    w_wino: the weight once more in Winograd form [16, Cout, Cin] (layers.HipConv3x3._winograd_weight / ca_pack_w_wino): the library
+    then runs the shapes it names as F(2x2, 3x3) (ca_conv_args.w_wino, ABI v12)."""
+    _req_cuda(x, w, x2, bias, rowbias, residual, w_wino)
     assert x.dim() == 4 and x.is_contiguous() and w.dim() == 4 and w.is_contiguous()
     images, hin, win, cin1 = x.shape
     cin2 = 0
@@ -320,6 +322,9 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
                     win=win, cin1=cin1, cin2=cin2, cout=cout, stride=stride, upsample=int(upsample),
                     rows_per_group=rows_per_group, alpha=alpha, post_scale=post_scale, act=act,
                     out_f32=int(out_f32), dtype=dt_code(x.dtype), pad_asym=int(pad_asym))
+    if w_wino is not None and dispatch.conv_winograd:
+        assert w_wino.dtype == x.dtype and w_wino.is_contiguous() and tuple(w_wino.shape) == (16, cout, cin1 + cin2)
+        args.w_wino = _p(w_wino)
     wbytes = int(lib().ca_conv3x3_workspace_bytes(C.byref(args)))
     if wbytes > 0:  # split-K slabs for the small-M levels (allocator-cached, stream-ordered)
         ws = torch.empty((wbytes,), device=x.device, dtype=torch.uint8)

@@ -21,6 +21,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
+from .context import dispatch
 
 ALIGN = 256  # bytes
 
@@ -202,6 +203,7 @@ class HipConv3x3(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels))
         nn.init.normal_(self.weight, std=(9 * in_channels) ** -0.5)
         self.w = self.b = None
+        self.winograd = True  # (False where the caller runs it with upsample / asymmetric padding: Upsample3D, the VAE's downsamplers)
 
     def _packed_weight(self) -> torch.Tensor:
         w = _f32(self.weight).permute(0, 2, 3, 1)  # [Cout, kh, kw, Cin]
@@ -209,12 +211,25 @@ class HipConv3x3(nn.Module):
             w = torch.nn.functional.pad(w, (0, self.cin_pad - self.in_channels))
         return w.contiguous()
 
+    def _winograd_weight(self) -> torch.Tensor:
+        """U [16, Cout, Cin] = G g G^T per (Cout, Cin) from the fp32 weights (one rounding to the activation type): F(2x2, 3x3),
+        csrc/ca_conv_wino.h."""
+        g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32, device=self.weight.device)
+        u = torch.einsum("xk,oikl,yl->xyoi", g, _f32(self.weight), g)  # weight [Cout, Cin, kh, kw]
+        return u.reshape(16, self.out_channels, self.in_channels).contiguous()
+
     def pack(self, arena: WeightArena, dtype):
         self.w = arena.add((self.out_channels, 3, 3, self.cin_pad), dtype, self._packed_weight)
         self.b = arena.add((self.out_channels,), torch.float32, lambda: _f32(self.bias))
+        # the deep stride-1 convolutions also in Winograd form: ca_conv3x3 takes it at the small-latent levels (ca_conv_args.w_wino, ABI v12)
+        self.u = None
+        if (dispatch.conv_winograd and self.stride == 1 and self.winograd and self.in_channels >= 1280 and self.in_channels % 64 == 0
+                and self.out_channels % 320 == 0 and dtype == torch.float16):
+            self.u = arena.add((16, self.out_channels, self.in_channels), dtype, self._winograd_weight)
 
     def run(self, x: torch.Tensor, **kw) -> torch.Tensor:
-        return K.conv3x3(x, self.w.t, bias=self.b.t, stride=self.stride, **kw)
+        u = getattr(self, "u", None)
+        return K.conv3x3(x, self.w.t, bias=self.b.t, stride=self.stride, w_wino=None if u is None else u.t, **kw)
 
 
 class HipGroupNorm(nn.Module):

@@ -311,7 +311,16 @@ typedef struct ca_conv_args {
    * (diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + Conv2d(stride=2), the VAE encoder's
    * downsamplers): Hout = (H + 1 - 3) / stride + 1. */
   int32_t pad_asym;
+  /* ABI v12: the weight once more in Winograd form, U [16][cout][cin1 + cin2] = G g G^T per (cout, cin) (written by ca_pack_w_wino
+   * from `w`), or NULL.  With it -- and a workspace of ca_conv3x3_workspace_bytes(args) bytes -- the deep convolutions of the small-latent
+   * levels (fp16, stride 1, padding 1, even H and W, cin >= 1280, cout % 320 == 0, images * H * W / 4 a multiple of 256 and at most
+   * 4096 tiles) run as F(2x2, 3x3): an input transform, ONE launch of the 256 x 320 GEMM kernel over the sixteen transformed GEMMs,
+   * an output transform that applies the epilogue.  2.25 x fewer multiply-adds; results differ from the direct form by fp16 rounding
+   * of the transformed operands (tests/test_kernels_gpu.py::test_conv3x3_winograd).  NULL / no workspace / another shape: the direct form. */
+  const void* w_wino;
 } ca_conv_args;
+/* ABI v12: dst[16 * cout * cin] = G g G^T of w [cout][3][3][cin] (the layout of ca_conv_args.w) in the element type `dtype`. */
+int ca_pack_w_wino(const void* w, int32_t cout, int32_t cin, int32_t dtype, void* dst, void* stream);
 int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* args);
 int ca_conv3x3(const ca_conv_args* args, void* stream);
 /* ABI v7: as ca_gemm_plan_name, for ca_conv3x3 */

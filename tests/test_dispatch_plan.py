@@ -306,3 +306,31 @@ ATTN_TABLE = [
 @pytest.mark.parametrize("kw,label", ATTN_TABLE, ids=[f"{l}-{k['nq']}x{k['nk']}-d{k['d']}" for k, l in ATTN_TABLE])
 def test_attention_dispatch(capi, kw, label):
     assert attn_label(capi, **kw) == label
+
+
+def test_winograd_route_of_the_deep_small_latent_convolutions(capi):
+    """ABI v12: with the Winograd weights and the workspace the 16x16- and 8x8-latent convolutions with >= 1280 input channels report
+    "wino_pq256x320"; without either, at 32x32 latents, for stride 2 / upsampling / bf16 they keep the direct kernels."""
+    def label(images, h, cin, cout, *, cin2=0, wino=True, workspace=True, stride=1, upsample=0, dtype=None):
+        a = capi.ConvArgs(x=FAKE, w=FAKE, y=FAKE, images=images, hin=h, win=h, cin1=cin - cin2, cin2=cin2, cout=cout, stride=stride,
+                          upsample=upsample, alpha=1.0, post_scale=1.0, dtype=capi.CA_F16 if dtype is None else dtype, rows_per_group=1)
+        if cin2:
+            a.x2 = FAKE
+        if wino:
+            a.w_wino = FAKE
+        if workspace:
+            a.workspace, a.workspace_bytes = FAKE, 1 << 40
+        buf = C.create_string_buffer(64)
+        assert capi.lib().ca_conv3x3_plan_name(C.byref(a), buf, 64) == 0, capi.lib().ca_last_error()
+        return buf.value.decode(), int(capi.lib().ca_conv3x3_workspace_bytes(C.byref(a)))
+    assert label(32, 16, 1280, 1280) == ("wino_pq256x320", 16 * 2048 * (1280 + 1280) * 2)
+    assert label(32, 16, 2560, 1280, cin2=1280)[0] == "wino_pq256x320"
+    assert label(32, 16, 1920, 1280, cin2=640)[0] == "wino_pq256x320"
+    assert label(32, 8, 1280, 1280)[0] == "wino_pq256x320"
+    assert label(32, 16, 1280, 1280, wino=False)[0] == "pp128x320"
+    assert label(32, 16, 1280, 1280, workspace=False)[0] == "pp128x320"
+    assert not label(32, 32, 1280, 1280)[0].startswith("wino")          # 8192 tiles: the direct form fills the chip
+    assert not label(32, 16, 640, 1280)[0].startswith("wino")           # shallow input: sixteen K = 640 GEMMs are epilogue-bound
+    assert not label(32, 16, 1280, 1280, stride=2)[0].startswith("wino")
+    assert not label(32, 8, 1280, 1280, upsample=1)[0].startswith("wino")
+    assert not label(32, 16, 1280, 1280, dtype=capi.CA_BF16)[0].startswith("wino")

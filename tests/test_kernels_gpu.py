@@ -901,3 +901,38 @@ def test_ff_fused_with_proj_out_c320(dtype):
     d = ff_check.make(16384 + 72, dtype)
     wo, bo = ff_check.make_out(dtype)
     assert ff_check.fused_out(d, wo, bo, None) is None
+
+
+@pytest.mark.gpu
+def test_conv3x3_winograd():
+    """The Winograd F(2x2, 3x3) route of ca_conv3x3 (ABI v12 w_wino, csrc/ca_conv_wino.h) on the shapes the plan gives it -- 16x16- and
+    8x8-latent resnet convolutions, single input and the skip concatenations, with and without the resnet epilogue (bias, time-embedding
+    row bias, residual, 1 / output_scale_factor) -- against fp32 torch (animatediff/models/resnet.py:12-20: nn.Conv2d per frame) and
+    beside the direct implicit-GEMM form; bit-reproducible; shapes outside its window take the direct form."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wino_check as W
+    k = _k()
+    for (images, h, c1, c2, cout) in [(32, 16, 1280, 0, 1280), (32, 16, 1280, 640, 1280), (32, 8, 1280, 1280, 1280), (16, 16, 1280, 640, 640)]:
+        for epi in (True, False):
+            d = W.make(images, h, c1, c2, cout, epilogue=epi)
+            k._plan_sink = labels = []
+            try:
+                y = W.run(d, True)
+                direct = W.run(d, False)
+            finally:
+                k._plan_sink = None
+            assert labels[0] == "wino_pq256x320" and not labels[1].startswith("wino"), labels
+            ref = W.reference(d)
+            rel = ((y.float() - ref).norm() / ref.norm()).item()
+            rel_d = ((direct.float() - ref).norm() / ref.norm()).item()
+            assert torch.isfinite(y.float()).all() and rel < 3e-3, (images, h, c1, c2, cout, epi, rel, rel_d)
+            assert torch.equal(y, W.run(d, True))
+    # outside the window: 32x32 latents (8192 tiles), a shallow input, stride 2 -> the direct kernels, whatever w_wino says
+    d = W.make(32, 32, 1280, 0, 640, epilogue=False)
+    k._plan_sink = labels = []
+    try:
+        W.run(d, True)
+    finally:
+        k._plan_sink = None
+    assert not labels[0].startswith("wino"), labels
