@@ -15,7 +15,8 @@
 //
 // V and M live in the caller's workspace (ca_conv3x3_workspace_bytes).  fp16 only: the input transform adds and subtracts pairs of
 // activations in packed fp16 (two roundings per V element; bf16 has no packed add and would lose 3 more bits per rounding).
-// Taken where it pays: stride 1, pad 1, even H and W, Cin >= 1280, Cout % 320 == 0, T % 256 == 0 (plan_conv_wino in ca_gemm.hip).
+// Taken where it pays: stride 1, pad 1 (optionally behind a nearest x2 upsampling), even H and W, Cin >= 1280, Cout % 320 == 0, T % 256 == 0,
+// at most 16384 tiles (wino_workspace_bytes in ca_gemm.hip).
 
 // dst[f][co][ci] = sum_{kh, kw} G[xi][kh] G[nu][kw] w[co][kh][kw][ci],  f = 4 xi + nu,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 template <int DT>
@@ -55,7 +56,8 @@ struct WinoParams {
   const float* rowbias;
   const u16* res;
   int64_t ld_res, ld_rowbias;
-  int images, h, w, c1, c2, cout;
+  int images, h, w, c1, c2, cout;  // h, w: the LOGICAL input = output size (twice the stored input with ups)
+  int ups;                         // 1: nearest x2 folded into the gather (Upsample3D: F.interpolate + conv, resnet.py:67-81)
   int rows_per_group;
   float alpha, post;
   int act;
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(256) void k_wino_in(WinoParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int wx = 2 * tx - 1 + j;
-      d[i][j] = (hy >= 0 && hy < p.h && wx >= 0 && wx < p.w) ? ld16(src + (((int64_t)img * p.h + hy) * p.w + wx) * cs + c0) : (u32x4){0u, 0u, 0u, 0u};
+      const int sh = p.h >> p.ups, sw = p.w >> p.ups;  // stored size
+      d[i][j] = (hy >= 0 && hy < p.h && wx >= 0 && wx < p.w) ? ld16(src + (((int64_t)img * sh + (hy >> p.ups)) * sw + (wx >> p.ups)) * cs + c0) : (u32x4){0u, 0u, 0u, 0u};
     }
   }
   // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3), then the same along the columns

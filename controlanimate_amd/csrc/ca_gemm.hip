@@ -954,14 +954,17 @@ extern "C" int ca_gemm_wants_finished_stats(const ca_gemm_args* a) {
 
 // The Winograd route of ca_conv3x3 (ca_conv_wino.h): 0 = not taken, else the workspace it needs (V [16][T][cin] + M [16][T][cout]).
 static int64_t wino_workspace_bytes(const ca_conv_args* a) {
-  if (!a || !a->w_wino || a->dtype != CA_F16 || a->stride != 1 || a->upsample || a->pad_asym || a->out_f32) return 0;
-  if (a->images <= 0 || a->hin < 2 || a->win < 2 || (a->hin & 1) || (a->win & 1)) return 0;
+  if (!a || !a->w_wino || a->dtype != CA_F16 || a->stride != 1 || a->pad_asym || a->out_f32) return 0;
+  if (a->upsample != 0 && a->upsample != 1) return 0;
+  const int h = a->hin << a->upsample, w = a->win << a->upsample;  // logical input = output size
+  if (a->images <= 0 || h < 2 || w < 2 || (h & 1) || (w & 1)) return 0;
   const int kc = a->cin1 + a->cin2;
   if (kc < 1280 || kc % BK != 0 || a->cin1 % 8 != 0 || a->cin2 % 8 != 0 || a->cout % 320 != 0) return 0;
-  const int64_t tiles = (int64_t)a->images * (a->hin / 2) * (a->win / 2);
-  // whole 256-row tiles per transformed GEMM, and the small-latent levels only (16x16 and 8x8 latents at 32 images): above that the
-  // direct form fills the chip with 256 x 320 tiles and the 4 x larger V / M tensors cost more than the saved MFMAs
-  static const int max_tiles = CA_KNOB("CA_WINO_MAX_TILES", 4096);
+  const int64_t tiles = (int64_t)a->images * (h / 2) * (w / 2);
+  // whole 256-row tiles per transformed GEMM.  Measured (tools/wino_check.py, us, Winograd vs direct): 32 x 16x16 1280->1280 170 vs 276,
+  // 2560->1280 285 vs 529, 32 x 8x8 1280->1280 66 vs 87, 32 x 32x32 1920->640 510 vs 584, 1280->1280 634 vs 800; with 640 input channels
+  // the sixteen K = 640 GEMMs are epilogue-bound and the 4 x larger V / M tensors cost more than the saved MFMAs (no gain): >= 1280 only
+  static const int max_tiles = CA_KNOB("CA_WINO_MAX_TILES", 16384);
   if (tiles % 256 != 0 || tiles > max_tiles) return 0;
   if (16 * tiles * (int64_t)(kc > a->cout ? kc : a->cout) * 2 >= 0x7FFFFF00ll) return 0;  // 32-bit byte offsets in the GEMM
   return 16 * tiles * (int64_t)(kc + a->cout) * 2;
@@ -1056,7 +1059,8 @@ static bool wino_taken(const ca_conv_args* a) {
 
 static int launch_conv_wino(const ca_conv_args* a, const GemmKParams& cp, hipStream_t st) {
   const int kc = a->cin1 + a->cin2;
-  const int64_t tiles = (int64_t)a->images * (a->hin / 2) * (a->win / 2);
+  const int hl = a->hin << a->upsample, wl = a->win << a->upsample;
+  const int64_t tiles = (int64_t)a->images * (hl / 2) * (wl / 2);
   WinoParams w{};
   w.x = (const u16*)a->x;
   w.x2 = (const u16*)a->x2;
@@ -1069,7 +1073,8 @@ static int launch_conv_wino(const ca_conv_args* a, const GemmKParams& cp, hipStr
   w.res = (const u16*)a->residual;
   w.ld_res = a->ld_res;
   w.ld_rowbias = a->ld_rowbias;
-  w.images = a->images, w.h = a->hin, w.w = a->win, w.c1 = a->cin1, w.c2 = a->cin2, w.cout = a->cout;
+  w.images = a->images, w.h = hl, w.w = wl, w.c1 = a->cin1, w.c2 = a->cin2, w.cout = a->cout;
+  w.ups = a->upsample;
   w.rows_per_group = cp.rows_per_group;
   w.alpha = a->alpha, w.post = a->post_scale, w.act = a->act;
   const int64_t in_threads = tiles * (kc / 8), out_threads = tiles * (a->cout / 8);

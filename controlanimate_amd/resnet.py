@@ -34,7 +34,6 @@ class Upsample3D(nn.Module):
         super().__init__()
         self.channels, self.out_channels = channels, out_channels or channels
         self.conv = InflatedConv3d(channels, self.out_channels)
-        self.conv.winograd = False  # (always run with the nearest x2 folded into its gather: the Winograd route does not take it)
 
     def pack(self, arena, dtype):
         self.conv.pack(arena, dtype)

@@ -329,8 +329,10 @@ def test_winograd_route_of_the_deep_small_latent_convolutions(capi):
     assert label(32, 8, 1280, 1280)[0] == "wino_pq256x320"
     assert label(32, 16, 1280, 1280, wino=False)[0] == "pp128x320"
     assert label(32, 16, 1280, 1280, workspace=False)[0] == "pp128x320"
-    assert not label(32, 32, 1280, 1280)[0].startswith("wino")          # 8192 tiles: the direct form fills the chip
+    assert label(32, 32, 1280, 1280)[0] == "wino_pq256x320"             # 8192 tiles: 634 vs 800 us (tools/wino_check.py)
+    assert label(32, 16, 1280, 1280, upsample=1)[0] == "wino_pq256x320"  # Upsample3D: the nearest x2 folded into the input transform
+    assert not label(64, 64, 1280, 1280)[0].startswith("wino")          # 65536 tiles: beyond the window
     assert not label(32, 16, 640, 1280)[0].startswith("wino")           # shallow input: sixteen K = 640 GEMMs are epilogue-bound
     assert not label(32, 16, 1280, 1280, stride=2)[0].startswith("wino")
-    assert not label(32, 8, 1280, 1280, upsample=1)[0].startswith("wino")
+    assert not label(32, 3, 1280, 1280, upsample=1)[0].startswith("wino")  # 6 x 6 logical: 288 tiles, not whole 256-row GEMM tiles
     assert not label(32, 16, 1280, 1280, dtype=capi.CA_BF16)[0].startswith("wino")

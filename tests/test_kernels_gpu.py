@@ -928,8 +928,22 @@ def test_conv3x3_winograd():
             rel_d = ((direct.float() - ref).norm() / ref.norm()).item()
             assert torch.isfinite(y.float()).all() and rel < 3e-3, (images, h, c1, c2, cout, epi, rel, rel_d)
             assert torch.equal(y, W.run(d, True))
-    # outside the window: 32x32 latents (8192 tiles), a shallow input, stride 2 -> the direct kernels, whatever w_wino says
-    d = W.make(32, 32, 1280, 0, 640, epilogue=False)
+    # Upsample3D: nearest x2 folded into the input transform (resnet.py:67-81), against F.interpolate + conv2d
+    import torch.nn.functional as F
+    d = W.make(32, 8, 1280, 0, 1280, epilogue=False)
+    k._plan_sink = labels = []
+    try:
+        y = k.conv3x3(d["x"], d["w"], upsample=True, w_wino=d["u"])
+        direct = k.conv3x3(d["x"], d["w"], upsample=True)
+    finally:
+        k._plan_sink = None
+    assert labels[0] == "wino_pq256x320" and not labels[1].startswith("wino"), labels
+    up = F.interpolate(d["x"].float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(up, d["w"].float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert tuple(y.shape) == (32, 16, 16, 1280)
+    assert ((y.float() - ref).norm() / ref.norm()).item() < 3e-3 and ((direct.float() - ref).norm() / ref.norm()).item() < 3e-3
+    # outside the window: a shallow input -> the direct kernels, whatever w_wino says
+    d = W.make(32, 16, 640, 0, 640, epilogue=False)
     k._plan_sink = labels = []
     try:
         W.run(d, True)
