@@ -173,8 +173,10 @@ def rocprof_kernel_name(family: str, dtype: str) -> str:
         return f"k_gemm_wres<{dt}>"
     if tile == "ar128x64":  # (every epilogue variant: k_gemm_ar<dt, EPI>)
         return f"k_gemm_ar<{dt}, "
-    if tile == "fused128":  # family "ff_fused128": both GEMMs of a feed-forward in one launch
-        return f"k_ff_fused<{dt}>"
+    if tile in ("fused128", "out128") and op == "ff":  # "ff_fused128" / "ff_out128": the feed-forward in one launch (+ proj_out, round 5)
+        return f"k_ff_fused<{dt}, {'true' if tile == 'out128' else 'false'}>"
+    if tile.startswith("wino_"):  # Winograd route: three kernels per call (k_wino_in, k_gemm_pq<dt, 0, 0>, k_wino_out) -- no single name
+        return ""
     if tile.startswith("pp128x320"):
         return f"k_gemm_pp2<{dt}, {mode}"
     if tile == "ps128x320":
@@ -182,6 +184,8 @@ def rocprof_kernel_name(family: str, dtype: str) -> str:
     if tile.startswith("pq256x320"):  # (every epilogue variant of the family: k_gemm_pq<dt, mode, EPI>)
         return f"k_gemm_pq<{dt}, {mode}"
     base = tile.split("_")[0]
+    if base.count("x") != 1 or not base.replace("x", "").isdigit():
+        return ""  # (a label this table does not know: no rocprof name, never a crash of the bench line)
     bm, bn = base.split("x")
     waves = "4, 1" if base == "128x64" else "2, 2"
     nbuf = 2 if tile.endswith("_db") else 3 if tile.endswith("_r3") else 4 if tile.endswith("_r4") else 1
@@ -194,8 +198,10 @@ def kernel_display_name(family: str) -> str:
         return f"k_gemm_wres<{family}>"
     if tile == "ar128x64":
         return f"k_gemm_ar<{family}>"
-    if tile == "fused128":
+    if tile in ("fused128", "out128") and family.startswith("ff_"):
         return f"k_ff_fused<{family}>"
+    if tile.startswith("wino_"):
+        return f"k_wino_in + k_gemm_pq + k_wino_out<{family}>"
     if tile.startswith("pp128x320"):
         return f"k_gemm_pp2<{family}>"
     if tile == "ps128x320":
@@ -205,7 +211,7 @@ def kernel_display_name(family: str) -> str:
     return f"k_gemm_dma<{family}>"
 
 
-PMC_SUMMARIES = ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
+PMC_SUMMARIES = ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
 
 
 def pmc_traffic(kernel_prefix: str, workload_key: str, dtype: str):
