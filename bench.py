@@ -300,8 +300,11 @@ class KernelTimer:
                 m, c = x.shape
                 inner = w2_frag.shape[1]
                 # x, y (+ residual) once, both weight matrices once; the [m, inner] intermediate never leaves the CU
-                timer.bytes[id(s)] = 2.0 * (m * c * (3 if kw.get("residual") is not None else 2) + 3 * inner * c)
-                timer.records.append(("ff_fused128", 2.0 * m * c * 2 * inner + 2.0 * m * inner * c, s, e, (m, 3 * inner, c)))
+                with_out = kw.get("w_out_frag") is not None  # round 5: + the transformer's proj_out (+ its residual) in the same launch
+                rows_io = (3 if kw.get("residual") is not None else 2) + (1 if with_out and kw.get("residual_out") is not None else 0)
+                timer.bytes[id(s)] = 2.0 * (m * c * rows_io + 3 * inner * c + (c * c if with_out else 0))
+                timer.records.append(("ff_out128" if with_out else "ff_fused128", 2.0 * m * c * 2 * inner + 2.0 * m * inner * c + (2.0 * m * c * c if with_out else 0.0),
+                                      s, e, (m, 3 * inner + (c if with_out else 0), c)))
             return out
 
         K.gemm, K.conv3x3, K.ff_fused = gemm, conv3x3, ff_fused
