@@ -235,7 +235,13 @@ extern "C" int ca_xattn_pack_kv(const void* kv, int64_t ld, int32_t kv_batches, 
 extern "C" int ca_xattn_fused_supported(const ca_xattn_args* a) {
   if (!a || !a->x || !a->wq_frag || !a->kv_frag || !a->o) return 0;
   if (a->c != 320 || a->heads != 8 || a->m < 16384 || a->tokens < 128 || a->tokens % 128 || a->m % a->tokens) return 0;
-  if (a->nk <= 64 || a->nk > 80 || a->frames_per_kv < 1 || a->kv_mod < 1 || a->kv_batches < a->kv_mod) return 0;
+  if (a->nk <= 64 || a->nk > 80 || a->frames_per_kv < 1 || a->kv_mod < 1) return 0;
+  {  // image z reads text batch (z / frames_per_kv) % kv_mod: the largest index used must exist among the packed batches
+    const int images = a->m / a->tokens;
+    const int groups = (images + a->frames_per_kv - 1) / a->frames_per_kv;
+    const int needed = groups < a->kv_mod ? groups : a->kv_mod;
+    if (a->kv_batches < needed) return 0;
+  }
   if (a->dtype != CA_BF16 && a->dtype != CA_F16) return 0;
   if (a->lda % 8 || a->ldo % 8 || a->lda < 320 || a->ldo < 320) return 0;
   if ((((uintptr_t)a->x | (uintptr_t)a->o | (uintptr_t)a->wq_frag | (uintptr_t)a->kv_frag | (uintptr_t)a->bias) & 15) != 0) return 0;

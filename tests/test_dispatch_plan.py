@@ -250,7 +250,10 @@ def test_fused_text_cross_attention_only_takes_what_it_implements(capi):
 
     assert ok() == 1 and ok(dtype=capi.CA_BF16) == 1 and ok(bias=None) == 1 and ok(nk=80) == 1 and ok(m=16384, tokens=1024) == 1 and ok(lda=640) == 1
     assert ok(nk=64) == 0 and ok(nk=81) == 0 and ok(heads=4) == 0 and ok(c=640) == 0 and ok(tokens=4100) == 0 and ok(m=131072 + 128) == 0
-    assert ok(m=8192, tokens=1024) == 0 and ok(kv_mod=3) == 0 and ok(frames_per_kv=0) == 0
+    assert ok(m=8192, tokens=1024) == 0 and ok(frames_per_kv=0) == 0
+    # image z reads text batch (z // frames_per_kv) % kv_mod: what counts is the largest index USED (32 images, 16 per prompt: 0 and 1)
+    assert ok(kv_mod=3) == 1 and ok(kv_mod=32) == 1          # (kv_mod = images is kernels.xattn_fused's default, as attention_cross)
+    assert ok(kv_mod=3, frames_per_kv=8) == 0 and ok(kv_mod=32, frames_per_kv=8) == 0 and ok(kv_batches=1) == 0
     assert ok(wq_frag=None) == 0 and ok(kv_frag=None) == 0 and ok(x=FAKE + 8) == 0 and ok(lda=324) == 0 and ok(ln_eps=0.0) == 0 and ok(dtype=7) == 0
     assert ok(m=1 << 23, tokens=4096) == 0  # 32-bit byte offsets
     bad = capi.XattnArgs(x=FAKE, m=5)

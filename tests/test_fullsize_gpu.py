@@ -120,6 +120,10 @@ def test_config2_full_size_eps_vs_oracle():
     print("kernel labels of the PRODUCT step:", pk)
     for need in ("ar128x64", "ff_out", "tattn_out", "xattn_out", "pq256x320", "attn_dma40", "attn_dma80", "attn_short", "wres160", "ps128x320"):
         assert any(k.startswith(need) for k in pk), f"the product step at config-2 size never ran `{need}`: {pk}"
+    # ... and at every site of the 64x64-latent level, not just once: 7 text cross-attentions (UNet 5 + ControlNet 2), 10 temporal
+    # attentions (5 motion modules x 2), 12 feed-forwards -- a `_supported` gate that declines SOME of them only costs time, silently
+    for label, sites in (("xattn_out128", 7), ("tattn_out128", 10), ("ff_out128", 12)):
+        assert pk.get(label, 0) >= sites, f"`{label}` ran {pk.get(label, 0)} times in the product step, expected {sites}: {pk}"
     del graph, eps_static, eps_eager
     del unet, net, cn, down, mid, out
     gc.collect()
