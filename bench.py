@@ -833,6 +833,18 @@ def main():
     }
     if not args.no_roofline:
         agg = timer.summary()
+        # Winograd route (round 5): the convolutions that take it execute 16 multiply-adds per 2 x 2 outputs instead of 36.  The
+        # algorithmic count (the reference's direct convolution) stays what throughput is quoted on; the EXECUTED count -- what the
+        # matrix pipes actually did -- is lower by 20 / 36 of those launches' direct FLOPs, and step_mfma_frac follows it.
+        wino = agg.get("conv3x3_wino_pq256x320")
+        if wino and wino["launches"]:
+            steps_instr = min(args.steps, 5, steps_per_window)
+            wino_direct_tflop = wino["flops"] / steps_instr * 1e-12
+            out["winograd"] = {"launches_per_step": round(wino["launches"] / steps_instr, 1), "direct_tflop_per_step": round(wino_direct_tflop, 3),
+                               "executed_tflop_per_step": round(wino_direct_tflop * 16.0 / 36.0, 3)}
+            executed = step_tflop - shared_tflop - wino_direct_tflop * 20.0 / 36.0
+            out["step_executed_tflop"] = round(executed, 2)
+            out["step_mfma_frac"] = round(executed / sec_per_step / PEAK_MFMA_TFLOPS, 4)
         if agg:
             dom = max(agg, key=lambda k: agg[k]["ms"])
             d = agg[dom]
