@@ -91,7 +91,7 @@ class ConvArgs(C.Structure):
         ("alpha", C.c_float), ("post_scale", C.c_float),
         ("act", C.c_int32), ("out_f32", C.c_int32), ("dtype", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("pad_asym", C.c_int32),
-        ("w_wino", C.c_void_p),  # ABI v12
+        ("w_wino", C.c_void_p), ("x_is_wino_v", C.c_int32),  # ABI v12
     ]
 
 
@@ -102,6 +102,7 @@ class GroupNormArgs(C.Structure):
         ("images", C.c_int32), ("hw", C.c_int32), ("c1", C.c_int32), ("c2", C.c_int32),
         ("groups", C.c_int32), ("frames_per_stat", C.c_int32),
         ("eps", C.c_float), ("act", C.c_int32), ("dtype", C.c_int32),
+        ("wino_v", C.c_void_p), ("wino_h", C.c_int32), ("wino_w", C.c_int32),  # ABI v12
     ]
 
 
@@ -163,6 +164,7 @@ SYMBOLS = {
     "ca_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),
     "ca_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),
     "ca_groupnorm": (C.c_int, [C.POINTER(GroupNormArgs), C.c_void_p]),
+    "ca_groupnorm_wino_supported": (C.c_int, [C.POINTER(GroupNormArgs)]),
     "ca_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "ca_attention": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "ca_attention_plan_name": (C.c_int, [C.POINTER(AttnArgs), C.c_char_p, C.c_int32]),

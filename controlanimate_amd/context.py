@@ -38,6 +38,7 @@ class Dispatch:
     xattn_fused = True    # ca_xattn_fused for the 64x64-latent text cross-attention
     attn_out_fused = True  # ... with the output projection + bias + residual as their last stage (ABI v12)
     conv_winograd = True  # Winograd F(2x2, 3x3) form of the deep convolutions at the small-latent levels (read at prepare() time)
+    gn_winograd = True    # ... with the GroupNorm in front writing the transformed input itself (ca_groupnorm_args.wino_v)
     ln_row_sums = True    # LayerNorm statistics from the producing GEMM's epilogue
     repeat_kernel = True  # ca_repeat instead of torch.cat for the CFG-shared prefix
     ln_fold = True        # LayerNorm folded into the projection it feeds

@@ -956,6 +956,7 @@ extern "C" int ca_gemm_wants_finished_stats(const ca_gemm_args* a) {
 static int64_t wino_workspace_bytes(const ca_conv_args* a) {
   if (!a || !a->w_wino || a->dtype != CA_F16 || a->stride != 1 || a->pad_asym || a->out_f32) return 0;
   if (a->upsample != 0 && a->upsample != 1) return 0;
+  if (a->x_is_wino_v && (a->cin2 != 0 || a->upsample)) return 0;
   const int h = a->hin << a->upsample, w = a->win << a->upsample;  // logical input = output size
   if (a->images <= 0 || h < 2 || w < 2 || (h & 1) || (w & 1)) return 0;
   const int kc = a->cin1 + a->cin2;
@@ -967,7 +968,7 @@ static int64_t wino_workspace_bytes(const ca_conv_args* a) {
   static const int max_tiles = CA_KNOB("CA_WINO_MAX_TILES", 16384);
   if (tiles % 256 != 0 || tiles > max_tiles) return 0;
   if (16 * tiles * (int64_t)(kc > a->cout ? kc : a->cout) * 2 >= 0x7FFFFF00ll) return 0;  // 32-bit byte offsets in the GEMM
-  return 16 * tiles * (int64_t)(kc + a->cout) * 2;
+  return 16 * tiles * (int64_t)((a->x_is_wino_v ? 0 : kc) + a->cout) * 2;  // V (unless the caller hands it over as x) + M
 }
 
 extern "C" int64_t ca_conv3x3_workspace_bytes(const ca_conv_args* a) {
@@ -1065,7 +1066,7 @@ static int launch_conv_wino(const ca_conv_args* a, const GemmKParams& cp, hipStr
   w.x = (const u16*)a->x;
   w.x2 = (const u16*)a->x2;
   w.v = (u16*)a->workspace;
-  u16* mm = (u16*)a->workspace + 16 * tiles * kc;
+  u16* mm = (u16*)a->workspace + (a->x_is_wino_v ? 0 : 16 * tiles * kc);
   w.mm = mm;
   w.y = (u16*)a->y;
   w.bias = a->bias;
@@ -1078,7 +1079,8 @@ static int launch_conv_wino(const ca_conv_args* a, const GemmKParams& cp, hipStr
   w.rows_per_group = cp.rows_per_group;
   w.alpha = a->alpha, w.post = a->post_scale, w.act = a->act;
   const int64_t in_threads = tiles * (kc / 8), out_threads = tiles * (a->cout / 8);
-  hipLaunchKernelGGL(k_wino_in, dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, st, w);
+  if (a->x_is_wino_v) w.v = (u16*)a->x;  // V was written by the GroupNorm in front (ca_groupnorm_args.wino_v)
+  else hipLaunchKernelGGL(k_wino_in, dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, st, w);
   // the sixteen transformed GEMMs as ONE launch of the 256 x 320 kernel: A = V [16 T, kc], weights U_f for the rows of group f
   GemmKParams q{};
   q.a = w.v;
@@ -1126,6 +1128,7 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
     CA_CHECK_LAUNCH("ca_conv3x3(winograd)");
     return CA_OK;
   }
+  CA_REQUIRE(!a->x_is_wino_v, "ca_conv3x3: x_is_wino_v, but the Winograd route does not take these arguments (w_wino, workspace, shape)");
   if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 1>(p, st);
   else launch_gemm<CA_F16, 1>(p, st);
   CA_CHECK_LAUNCH("ca_conv3x3");

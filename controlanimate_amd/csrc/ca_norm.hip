@@ -33,6 +33,10 @@ struct GnParams {
   int64_t rows_per_chunk;  // rows per block of the kernel being launched
   float eps;
   int act;
+  // round 5 (ABI v12): the fused one-launch kernel writes the Winograd F(2x2, 3x3) INPUT TRANSFORM of the normalised activations
+  // (V [16][T][C], csrc/ca_conv_wino.h) instead of y: the image is wino_h x wino_w pixels, T = images * (h / 2) * (w / 2)
+  u16* wino_v;
+  int wino_h, wino_w;
 };
 
 // Thread mapping: tx = lane over 16-byte channel chunks, ty = lane over rows; TX = 2^txlog in {8,16,32,64} is the
@@ -383,6 +387,140 @@ __global__ __launch_bounds__(256) void k_gn_small(GnParams p) {
         f[j] = p.act == CA_ACT_SILU ? silu_f(v) : v;
       }
       st16(p.y + (base_row + row) * C + ch, pack8<DT>(f));
+    }
+  }
+}
+
+// k_gn_small whose output is the Winograd input transform of GroupNorm(+SiLU)(x) (round 5): the block that owns (norm group g, image)
+// has every pixel of its cpg channels on chip, so instead of writing y for a transform kernel to read back (csrc/ca_conv_wino.h:
+// k_wino_in), it puts the normalised slab into LDS ([pixel][cpg] fp16, <= 40 KB) and writes B^T d B of every 4 x 4 neighbourhood
+// straight into V [16][T][C] -- the convolution behind it (ca_conv_args.x_is_wino_v) starts at its GEMM.  fp16 only (packed adds).
+__device__ __forceinline__ unsigned gnw_pk_add(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned gnw_pk_sub(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+constexpr int GNW_MAX_ROWS = 256, GNW_MAX_CPG = 80;
+__global__ __launch_bounds__(256) void k_gn_small_wino(GnParams p) {
+  constexpr int DT = CA_F16;
+  __shared__ double red[4][2];
+  __shared__ float mr[2];
+  __shared__ __attribute__((aligned(16))) u16 slab[GNW_MAX_ROWS * GNW_MAX_CPG];
+  const int C = p.c1 + p.c2;
+  const int cpg = C / p.groups, q = cpg >> 3;
+  const int g = blockIdx.x, sg = blockIdx.y;  // (frames_per_stat == 1: statistics group = image)
+  const int total = (int)p.rows_per_stat * q;
+  const int64_t base_row = (int64_t)sg * p.rows_per_stat;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4 raw[GNS_MAX];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < GNS_MAX; ++k) {
+    const int id = threadIdx.x + k * 256;
+    if (id < total) {
+      const int row = id / q, ch = g * cpg + (id - row * q) * 8;
+      const int64_t rr = base_row + row;
+      raw[k] = ld16(ch < p.c1 ? p.x + rr * p.c1 + ch : p.x2 + rr * p.c2 + (ch - p.c1));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < GNS_MAX; ++k) {
+    if (threadIdx.x + k * 256 < total) {
+      float f[8];
+      unpack8<DT>(raw[k], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s += f[j];
+        ss += f[j] * f[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    s += __shfl_xor(s, off);
+    ss += __shfl_xor(ss, off);
+  }
+  if (lane == 0) {
+    red[wave][0] = (double)s;
+    red[wave][1] = (double)ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double a = red[0][0] + red[1][0] + red[2][0] + red[3][0], b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    const double cnt = (double)p.rows_per_stat * (double)cpg;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[0] = (float)mean;
+    mr[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  const float mean = mr[0], rstd = mr[1];
+#pragma unroll
+  for (int k = 0; k < GNS_MAX; ++k) {
+    const int id = threadIdx.x + k * 256;
+    if (id < total) {
+      const int row = id / q, cq = id - row * q, ch = g * cpg + cq * 8;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + ch), g1 = *reinterpret_cast<const f32x4*>(p.gamma + ch + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + ch), b1 = *reinterpret_cast<const f32x4*>(p.beta + ch + 4);
+      float f[8];
+      unpack8<DT>(raw[k], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float scale = rstd * (j < 4 ? g0[j & 3] : g1[j & 3]);
+        const float v = f[j] * scale + ((j < 4 ? b0[j & 3] : b1[j & 3]) - mean * scale);
+        f[j] = p.act == CA_ACT_SILU ? silu_f(v) : v;
+      }
+      st16(slab + (row * q + cq) * 8, pack8<DT>(f));  // (exactly the values k_gn_small stores to y)
+    }
+  }
+  __syncthreads();
+  // ---- B^T d B per (tile, chunk): as k_wino_in, reading the slab
+  const int th = p.wino_h >> 1, tw = p.wino_w >> 1;
+  const int items = th * tw * q;
+  const int64_t tiles_total = (int64_t)gridDim.y * th * tw;
+  const int64_t fstride = tiles_total * C;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int cq = it % q, t = it / q;
+    const int tx = t % tw, ty = t / tw;
+    u32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hy = 2 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int wx = 2 * tx - 1 + j;
+        d[i][j] = (hy >= 0 && hy < p.wino_h && wx >= 0 && wx < p.wino_w) ? ld16(slab + ((hy * p.wino_w + wx) * q + cq) * 8) : (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+    u32x4 r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r[0][j][e] = gnw_pk_sub(d[0][j][e], d[2][j][e]);
+        r[1][j][e] = gnw_pk_add(d[1][j][e], d[2][j][e]);
+        r[2][j][e] = gnw_pk_sub(d[2][j][e], d[1][j][e]);
+        r[3][j][e] = gnw_pk_sub(d[1][j][e], d[3][j][e]);
+      }
+    u16* dst = p.wino_v + ((int64_t)sg * th * tw + t) * C + g * cpg + cq * 8;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      u32x4 o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[0][e] = gnw_pk_sub(r[xi][0][e], r[xi][2][e]);
+        o[1][e] = gnw_pk_add(r[xi][1][e], r[xi][2][e]);
+        o[2][e] = gnw_pk_sub(r[xi][2][e], r[xi][1][e]);
+        o[3][e] = gnw_pk_sub(r[xi][1][e], r[xi][3][e]);
+      }
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) st16(dst + (int64_t)(xi * 4 + nu) * fstride, o[nu]);
     }
   }
 }
@@ -808,10 +946,43 @@ extern "C" int ca_groupnorm_apply(const ca_groupnorm_args* a, void* stream) {
   return CA_OK;
 }
 
+// 1 if ca_groupnorm can write the Winograd input transform instead of y for these arguments (wino_v / wino_h / wino_w set): the
+// one-launch kernel's shapes with per-image statistics, fp16, an even wino_h x wino_w = hw image of at most 256 pixels, <= 80 channels
+// per norm group.  No launch, no device access.
+extern "C" int ca_groupnorm_wino_supported(const ca_groupnorm_args* a) {
+  if (!a || !a->x || !a->gamma || !a->beta || !a->wino_v || a->dtype != CA_F16 || a->frames_per_stat != 1) return 0;
+  if (a->images <= 0 || a->c1 <= 0 || a->c1 % 8 || a->c2 < 0 || a->c2 % 8 || (a->c2 && !a->x2) || a->groups <= 0) return 0;
+  const int C = a->c1 + a->c2;
+  if (C % a->groups) return 0;
+  const int cpg = C / a->groups;
+  if (cpg % 8 || cpg > GNW_MAX_CPG || (a->c2 != 0 && a->c1 % cpg != 0)) return 0;
+  if (a->wino_h < 2 || a->wino_w < 2 || (a->wino_h & 1) || (a->wino_w & 1) || a->wino_h * a->wino_w != a->hw || a->hw > GNW_MAX_ROWS) return 0;
+  if ((int64_t)a->hw * (cpg >> 3) > 256 * GNS_MAX) return 0;
+  if ((((uintptr_t)a->wino_v | (uintptr_t)a->x | (uintptr_t)a->x2) & 15) != 0) return 0;
+  return 1;
+}
+
 // GroupNorm in one call: the fused single-launch kernel where a statistics group fits a block's registers, otherwise
 // statistics + apply (needs `partials`).
 extern "C" int ca_groupnorm(const ca_groupnorm_args* a, void* stream) {
   GnParams p{};
+  if (a && a->wino_v) {  // ABI v12: the Winograd input transform of the normalised activations instead of y
+    CA_REQUIRE(ca_groupnorm_wino_supported(a), "ca_groupnorm: wino_v with arguments outside the fused form (fp16, per-image statistics, even image of <= 256 pixels, "
+                                                "<= 80 channels per group in whole 8-channel chunks): ask ca_groupnorm_wino_supported() first");
+    p.x = (const u16*)a->x;
+    p.x2 = (const u16*)a->x2;
+    p.gamma = a->gamma;
+    p.beta = a->beta;
+    p.c1 = a->c1, p.c2 = a->c2, p.groups = a->groups;
+    p.rows_per_stat = a->hw;
+    p.eps = a->eps;
+    p.act = a->act;
+    p.wino_v = (u16*)a->wino_v;
+    p.wino_h = a->wino_h, p.wino_w = a->wino_w;
+    hipLaunchKernelGGL(k_gn_small_wino, dim3(a->groups, a->images), dim3(256), 0, (hipStream_t)stream, p);
+    CA_CHECK_LAUNCH("ca_groupnorm(wino)");
+    return CA_OK;
+  }
   int rc = gn_fill(a, p, "ca_groupnorm");
   if (rc) return rc;
   CA_REQUIRE(a->y && a->gamma && a->beta, "ca_groupnorm: null operand");

@@ -334,6 +334,46 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
     return y
 
 
+def group_norm_conv3x3_wino(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor, w_wino: torch.Tensor, *,
+                            x2: Optional[torch.Tensor] = None, groups: int = 32, eps: float = 1e-5, act: int = ACT_NONE,
+                            bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None, rows_per_group: int = 0,
+                            residual: Optional[torch.Tensor] = None, post_scale: float = 1.0) -> Optional[torch.Tensor]:
+    """conv3x3(GroupNorm(+act)(cat(x, x2))) where the convolution takes the Winograd route AND the one-launch GroupNorm applies: the
+    GroupNorm writes the transformed input V itself (ca_groupnorm_args.wino_v, ABI v12) and the convolution starts at its GEMM
+    (ca_conv_args.x_is_wino_v) -- the normalised tensor is never written.  Per-image statistics only.  None where either side
+    declines: the caller runs group_norm, then conv3x3."""
+    if not (dispatch.conv_winograd and dispatch.gn_winograd):
+        return None
+    _req_cuda(x, gamma, beta, w, w_wino, x2, bias, rowbias, residual)
+    if x.dim() != 4 or not x.is_contiguous() or x.dtype != torch.float16 or (x2 is not None and (not x2.is_contiguous() or x2.shape[:3] != x.shape[:3])):
+        return None
+    images, h, w_, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    c, cout = c1 + c2, w.shape[0]
+    tiles = images * (h // 2) * (w_ // 2)
+    y = torch.empty((images, h, w_, cout), device=x.device, dtype=x.dtype)
+    v = torch.empty((16, tiles, c), device=x.device, dtype=x.dtype)
+    cargs = ConvArgs(x=_p(v), x2=None, w=_p(w), y=_p(y), bias=_p(bias), rowbias=_p(rowbias), residual=_p(residual),
+                     ld_res=cout if residual is not None else 0, ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, images=images, hin=h,
+                     win=w_, cin1=c, cin2=0, cout=cout, stride=1, upsample=0, rows_per_group=rows_per_group, alpha=1.0, post_scale=post_scale,
+                     act=ACT_NONE, out_f32=0, dtype=dt_code(x.dtype), pad_asym=0, w_wino=_p(w_wino), x_is_wino_v=1)
+    wbytes = int(lib().ca_conv3x3_workspace_bytes(C.byref(cargs)))
+    gargs = GroupNormArgs(x=_p(x), x2=_p(x2), y=None, gamma=_p(gamma), beta=_p(beta), partials=None, images=images, hw=h * w_, c1=c1, c2=c2,
+                          groups=groups, frames_per_stat=1, eps=eps, act=act, dtype=dt_code(x.dtype), wino_v=_p(v), wino_h=h, wino_w=w_)
+    if wbytes <= 0 or not lib().ca_groupnorm_wino_supported(C.byref(gargs)):
+        return None
+    if residual is not None:
+        assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == y.numel()
+    ws = torch.empty((wbytes,), device=x.device, dtype=torch.uint8)
+    cargs.workspace, cargs.workspace_bytes = _p(ws), wbytes
+    if _plan_sink is not None:
+        buf = C.create_string_buffer(64)
+        _plan_sink.append("gn_" + (buf.value.decode() if lib().ca_conv3x3_plan_name(C.byref(cargs), buf, 64) == 0 else "?"))
+    check(lib().ca_groupnorm(C.byref(gargs), _stream()), "ca_groupnorm(wino)")
+    check(lib().ca_conv3x3(C.byref(cargs), _stream()), "ca_conv3x3(wino, V given)")
+    return y
+
+
 def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, x2: Optional[torch.Tensor] = None,
                groups: int = 32, frames_per_stat: int = 1, eps: float = 1e-5, act: int = ACT_NONE) -> torch.Tensor:
     """GroupNorm (+SiLU) over NHWC x (optionally channel-concatenated with x2)."""

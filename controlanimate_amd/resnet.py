@@ -81,14 +81,28 @@ class ResnetBlock3D(nn.Module):
     def forward(self, x: torch.Tensor, ctx: ExecCtx, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [images,h,w,c1] (+ skip [images,h,w,c2] standing for torch.cat([x, skip], dim=1))."""
         images, h, w, _ = x.shape
-        h1 = self.norm1.run(x, x2=skip, frames_per_stat=ctx.gn_frames_per_stat, act=K.ACT_SILU)
         lo, hi = self.temb_slice
-        h1 = self.conv1.run(h1, rowbias=ctx.temb[:, lo:hi], rows_per_group=ctx.rows_per_emb_group(h, w))
-        h1 = self.norm2.run(h1, frames_per_stat=ctx.gn_frames_per_stat, act=K.ACT_SILU)
+        kw1 = dict(rowbias=ctx.temb[:, lo:hi], rows_per_group=ctx.rows_per_emb_group(h, w))
+        h1 = self._norm_conv(self.norm1, self.conv1, x, skip, ctx, **kw1)
         if self.conv_shortcut is not None:
             rows = images * h * w
             res = self.conv_shortcut.run(x.view(rows, x.shape[3]), a2=None if skip is None else skip.view(rows, skip.shape[3]))
         else:
             assert skip is None
             res = x
-        return self.conv2.run(h1, residual=res.view(images, h, w, self.out_channels), post_scale=1.0 / self.output_scale_factor)
+        return self._norm_conv(self.norm2, self.conv2, h1, None, ctx, residual=res.view(images, h, w, self.out_channels),
+                               post_scale=1.0 / self.output_scale_factor)
+
+    @staticmethod
+    def _norm_conv(norm, conv, x, skip, ctx: ExecCtx, **conv_kw) -> torch.Tensor:
+        """conv(silu(norm(cat(x, skip)))) (reference :188-212).  Where the convolution takes the Winograd route and the one-launch
+        GroupNorm applies (per-frame statistics, the 8x8- / 16x16-latent levels) the GroupNorm writes the convolution's transformed
+        input itself: K.group_norm_conv3x3_wino."""
+        u = getattr(conv, "u", None)
+        if u is not None and ctx.gn_frames_per_stat == 1:
+            y = K.group_norm_conv3x3_wino(x, norm.g.t, norm.b.t, conv.w.t, u.t, x2=skip, groups=norm.num_groups, eps=norm.eps, act=K.ACT_SILU,
+                                          bias=conv.b.t, **conv_kw)
+            if y is not None:
+                return y
+        h = norm.run(x, x2=skip, frames_per_stat=ctx.gn_frames_per_stat, act=K.ACT_SILU)
+        return conv.run(h, **conv_kw)

@@ -318,6 +318,10 @@ typedef struct ca_conv_args {
    * an output transform that applies the epilogue.  2.25 x fewer multiply-adds; results differ from the direct form by fp16 rounding
    * of the transformed operands (tests/test_kernels_gpu.py::test_conv3x3_winograd).  NULL / no workspace / another shape: the direct form. */
   const void* w_wino;
+  /* ABI v12: 1 = `x` IS the transformed input V [16][tiles][cin1] already (written by ca_groupnorm's wino_v; cin2 = 0): the Winograd
+   * route starts at its GEMM.  The call fails unless the route is taken (w_wino, workspace, shape); the workspace then holds M only
+   * (ca_conv3x3_workspace_bytes says how much). */
+  int32_t x_is_wino_v;
 } ca_conv_args;
 /* ABI v12: dst[16 * cout * cin] = G g G^T of w [cout][3][3][cin] (the layout of ca_conv_args.w) in the element type `dtype`. */
 int ca_pack_w_wino(const void* w, int32_t cout, int32_t cin, int32_t dtype, void* dst, void* stream);
@@ -353,7 +357,15 @@ typedef struct ca_groupnorm_args {
   float eps;
   int32_t act;          /* CA_ACT_NONE / CA_ACT_SILU */
   int32_t dtype;
+  /* ABI v12 (ca_groupnorm only): with wino_v the launch writes, INSTEAD of y, the Winograd F(2x2, 3x3) input transform of the
+   * normalised (+ activated) tensor -- V [16][images * (wino_h / 2) * (wino_w / 2)][c1 + c2], what ca_conv3x3's Winograd route computes
+   * from y as its first stage -- so that the convolution behind it (ca_conv_args.x_is_wino_v) starts at its GEMM and y never exists
+   * (ResnetBlock3D: norm -> nonlinearity -> conv, animatediff/models/resnet.py:188-212).  hw = wino_h * wino_w.  Only where
+   * ca_groupnorm_wino_supported(args) says 1; y and partials are unused then. */
+  void* wino_v;
+  int32_t wino_h, wino_w;
 } ca_groupnorm_args;
+int ca_groupnorm_wino_supported(const ca_groupnorm_args* args);
 int64_t ca_groupnorm_partials_floats(int32_t images, int32_t hw, int32_t frames_per_stat, int32_t groups);
 int ca_groupnorm_stats(const ca_groupnorm_args* args, void* stream);
 int ca_groupnorm_apply(const ca_groupnorm_args* args, void* stream);

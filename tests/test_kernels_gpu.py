@@ -950,3 +950,44 @@ def test_conv3x3_winograd():
     finally:
         k._plan_sink = None
     assert not labels[0].startswith("wino"), labels
+
+
+@pytest.mark.gpu
+def test_groupnorm_writes_the_winograd_input_transform():
+    """ca_groupnorm with wino_v + ca_conv3x3 with x_is_wino_v (ABI v12): GroupNorm + SiLU whose output IS the Winograd route's transformed
+    input, so the normalised tensor is never written -- bit-identical to GroupNorm, then the Winograd convolution (the same values go
+    through the same packed-fp16 transform), single input and the skip concatenation, 16x16 and 8x8 latents; declined (None) where the
+    one-launch GroupNorm or the Winograd route does not apply."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wino_check as W
+    k = _k()
+    for (images, h, c1, c2, cout) in [(32, 16, 1280, 0, 1280), (32, 16, 1280, 1280, 1280), (32, 8, 1280, 1280, 1280), (16, 16, 1280, 0, 640)]:
+        d = W.make(images, h, c1, c2, cout, epilogue=True)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        gamma = (1.0 + 0.2 * torch.randn(c1 + c2, generator=g)).to(DEV)
+        beta = (0.1 * torch.randn(c1 + c2, generator=g)).to(DEV)
+        k._plan_sink = labels = []
+        try:
+            y = k.group_norm_conv3x3_wino(d["x"], gamma, beta, d["w"], d["u"], x2=d["x2"], act=k.ACT_SILU, eps=1e-6, bias=d["bias"], rowbias=d["rowbias"],
+                                          rows_per_group=d["rows_per_group"], residual=d["residual"], post_scale=d["post"])
+        finally:
+            k._plan_sink = None
+        assert y is not None and labels == ["gn_wino_pq256x320"], labels
+        hn = k.group_norm(d["x"], gamma, beta, x2=d["x2"], eps=1e-6, act=k.ACT_SILU)
+        two = k.conv3x3(hn, d["w"], bias=d["bias"], rowbias=d["rowbias"], rows_per_group=d["rows_per_group"], residual=d["residual"],
+                        post_scale=d["post"], w_wino=d["u"])
+        assert torch.equal(y, two), f"{int((y != two).sum())} of {y.numel()} elements differ"
+        # ... and right: against fp32 torch
+        import torch.nn.functional as F
+        xin = d["x"].float() if d["x2"] is None else torch.cat([d["x"].float(), d["x2"].float()], dim=-1)
+        ref_h = F.silu(F.group_norm(xin.permute(0, 3, 1, 2), 32, gamma, beta, 1e-6)).permute(0, 2, 3, 1)
+        dd = dict(d, x=ref_h.to(torch.float16), x2=None)
+        dd["w"] = d["w"]
+        ref = W.reference(dd)
+        assert ((y.float() - ref).norm() / ref.norm()).item() < 3e-3
+    # declined: 60 channels per group (C = 1920) is not whole 8-channel chunks; a 32x32 image does not fit the one-launch GroupNorm
+    for (images, h, c1, c2, cout) in [(32, 16, 1280, 640, 1280), (8, 32, 1280, 0, 1280)]:
+        d = W.make(images, h, c1, c2, cout, epilogue=False)
+        gamma, beta = torch.ones(c1 + c2, device=DEV), torch.zeros(c1 + c2, device=DEV)
+        assert k.group_norm_conv3x3_wino(d["x"], gamma, beta, d["w"], d["u"], x2=d["x2"], act=k.ACT_SILU) is None

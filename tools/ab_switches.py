@@ -13,6 +13,7 @@ ENV = {
     "CA_XATTN_FUSED": "xattn_fused",
     "CA_ATTN_OUT_FUSED": "attn_out_fused",
     "CA_CONV_WINOGRAD": "conv_winograd",
+    "CA_GN_WINOGRAD": "gn_winograd",
     "CA_LN_ROWSUMS": "ln_row_sums",
     "CA_REPEAT_KERNEL": "repeat_kernel",
     "CA_LN_FOLD": "ln_fold",
