@@ -13,8 +13,8 @@
 //   k_gemm_pq   V [16 T, C] x U [16][Cout][C]        -> M [16][T][Cout]            (fp16, rounded once per product sum as any GEMM output)
 //   k_wino_out  M                                    -> y [images, H, W, Cout]     fp32: A^T M A, bias, row bias, alpha, residual, post, activation
 //
-// V and M live in the caller's workspace (ca_conv3x3_workspace_bytes).  fp16 only: the input transform adds and subtracts pairs of
-// activations in packed fp16 (two roundings per V element; bf16 has no packed add and would lose 3 more bits per rounding).
+// V and M live in the caller's workspace (ca_conv3x3_workspace_bytes).  The input transform adds and subtracts pairs of activations:
+// packed fp16 arithmetic (two roundings per V element) or, for bf16, fp32 arithmetic rounded per operation.
 // Taken where it pays: stride 1, pad 1 (optionally behind a nearest x2 upsampling), even H and W, Cin >= 1280, Cout % 320 == 0, T % 256 == 0,
 // at most 16384 tiles (wino_workspace_bytes in ca_gemm.hip).
 
@@ -74,7 +74,20 @@ __device__ __forceinline__ unsigned wino_pk_sub(unsigned a, unsigned b) {
   return r;
 }
 
+// a +- b on a register of two 16-bit elements: fp16 packed (one rounding per operation); bf16 through fp32 (there is no packed bf16 add)
+template <int DT>
+__device__ __forceinline__ unsigned wino_add2(unsigned a, unsigned b) {
+  if (DT == CA_F16) return wino_pk_add(a, b);
+  return pack2<DT>(Elem<DT>::to_f((u16)(a & 0xffffu)) + Elem<DT>::to_f((u16)(b & 0xffffu)), Elem<DT>::to_f((u16)(a >> 16)) + Elem<DT>::to_f((u16)(b >> 16)));
+}
+template <int DT>
+__device__ __forceinline__ unsigned wino_sub2(unsigned a, unsigned b) {
+  if (DT == CA_F16) return wino_pk_sub(a, b);
+  return pack2<DT>(Elem<DT>::to_f((u16)(a & 0xffffu)) - Elem<DT>::to_f((u16)(b & 0xffffu)), Elem<DT>::to_f((u16)(a >> 16)) - Elem<DT>::to_f((u16)(b >> 16)));
+}
+
 // one thread = one (tile, 8-channel chunk): 16 pieces in, 16 pieces out; chunk index fastest (coalesced rows of V)
+template <int DT>
 __global__ __launch_bounds__(256) void k_wino_in(WinoParams p) {
   const int c = p.c1 + p.c2;
   const int chunks = c >> 3;
@@ -108,10 +121,10 @@ __global__ __launch_bounds__(256) void k_wino_in(WinoParams p) {
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      r[0][j][e] = wino_pk_sub(d[0][j][e], d[2][j][e]);
-      r[1][j][e] = wino_pk_add(d[1][j][e], d[2][j][e]);
-      r[2][j][e] = wino_pk_sub(d[2][j][e], d[1][j][e]);
-      r[3][j][e] = wino_pk_sub(d[1][j][e], d[3][j][e]);
+      r[0][j][e] = wino_sub2<DT>(d[0][j][e], d[2][j][e]);
+      r[1][j][e] = wino_add2<DT>(d[1][j][e], d[2][j][e]);
+      r[2][j][e] = wino_sub2<DT>(d[2][j][e], d[1][j][e]);
+      r[3][j][e] = wino_sub2<DT>(d[1][j][e], d[3][j][e]);
     }
   const int64_t fstride = tiles * c;
   u16* dst = p.v + t * c + ck * 8;
@@ -120,10 +133,10 @@ __global__ __launch_bounds__(256) void k_wino_in(WinoParams p) {
     u32x4 o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[0][e] = wino_pk_sub(r[xi][0][e], r[xi][2][e]);
-      o[1][e] = wino_pk_add(r[xi][1][e], r[xi][2][e]);
-      o[2][e] = wino_pk_sub(r[xi][2][e], r[xi][1][e]);
-      o[3][e] = wino_pk_sub(r[xi][1][e], r[xi][3][e]);
+      o[0][e] = wino_sub2<DT>(r[xi][0][e], r[xi][2][e]);
+      o[1][e] = wino_add2<DT>(r[xi][1][e], r[xi][2][e]);
+      o[2][e] = wino_sub2<DT>(r[xi][2][e], r[xi][1][e]);
+      o[3][e] = wino_sub2<DT>(r[xi][1][e], r[xi][3][e]);
     }
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) st16(dst + (int64_t)(xi * 4 + nu) * fstride, o[nu]);

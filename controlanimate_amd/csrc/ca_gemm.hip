@@ -954,7 +954,7 @@ extern "C" int ca_gemm_wants_finished_stats(const ca_gemm_args* a) {
 
 // The Winograd route of ca_conv3x3 (ca_conv_wino.h): 0 = not taken, else the workspace it needs (V [16][T][cin] + M [16][T][cout]).
 static int64_t wino_workspace_bytes(const ca_conv_args* a) {
-  if (!a || !a->w_wino || a->dtype != CA_F16 || a->stride != 1 || a->pad_asym || a->out_f32) return 0;
+  if (!a || !a->w_wino || (a->dtype != CA_F16 && a->dtype != CA_BF16) || a->stride != 1 || a->pad_asym || a->out_f32) return 0;
   if (a->upsample != 0 && a->upsample != 1) return 0;
   if (a->x_is_wino_v && (a->cin2 != 0 || a->upsample)) return 0;
   const int h = a->hin << a->upsample, w = a->win << a->upsample;  // logical input = output size
@@ -1080,7 +1080,8 @@ static int launch_conv_wino(const ca_conv_args* a, const GemmKParams& cp, hipStr
   w.alpha = a->alpha, w.post = a->post_scale, w.act = a->act;
   const int64_t in_threads = tiles * (kc / 8), out_threads = tiles * (a->cout / 8);
   if (a->x_is_wino_v) w.v = (u16*)a->x;  // V was written by the GroupNorm in front (ca_groupnorm_args.wino_v)
-  else hipLaunchKernelGGL(k_wino_in, dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, st, w);
+  else if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_wino_in<CA_BF16>), dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, st, w);
+  else hipLaunchKernelGGL((k_wino_in<CA_F16>), dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, st, w);
   // the sixteen transformed GEMMs as ONE launch of the 256 x 320 kernel: A = V [16 T, kc], weights U_f for the rows of group f
   GemmKParams q{};
   q.a = w.v;
@@ -1101,9 +1102,10 @@ static int launch_conv_wino(const ca_conv_args* a, const GemmKParams& cp, hipStr
   q.w_group_rows = (int)tiles;
   q.w_group_stride = (unsigned)((int64_t)a->cout * kc * 2);
   const unsigned gemm_tiles = (unsigned)((q.m / 256) * (q.n / 320));
-  int rc = ca_launch_gemm_pp(q, CA_F16, 0, 323, gemm_tiles, st);
+  int rc = ca_launch_gemm_pp(q, a->dtype, 0, 323, gemm_tiles, st);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_wino_out<CA_F16>), dim3((unsigned)((out_threads + 255) / 256)), dim3(256), 0, st, w);
+  if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_wino_out<CA_BF16>), dim3((unsigned)((out_threads + 255) / 256)), dim3(256), 0, st, w);
+  else hipLaunchKernelGGL((k_wino_out<CA_F16>), dim3((unsigned)((out_threads + 255) / 256)), dim3(256), 0, st, w);
   return CA_OK;
 }
 
@@ -1128,7 +1130,9 @@ extern "C" int ca_conv3x3(const ca_conv_args* a, void* stream) {
     CA_CHECK_LAUNCH("ca_conv3x3(winograd)");
     return CA_OK;
   }
-  CA_REQUIRE(!a->x_is_wino_v, "ca_conv3x3: x_is_wino_v, but the Winograd route does not take these arguments (w_wino, workspace, shape)");
+  CA_REQUIRE(!a->x_is_wino_v, "ca_conv3x3: x_is_wino_v, but the Winograd route does not take these arguments (images=%d %dx%d cin=%d+%d cout=%d dtype=%d w_wino=%p "
+             "workspace=%p of %lld bytes, needs %lld)", a->images, a->hin, a->win, a->cin1, a->cin2, a->cout, a->dtype, a->w_wino, a->workspace,
+             (long long)a->workspace_bytes, (long long)wino_workspace_bytes(a));
   if (a->dtype == CA_BF16) launch_gemm<CA_BF16, 1>(p, st);
   else launch_gemm<CA_F16, 1>(p, st);
   CA_CHECK_LAUNCH("ca_conv3x3");

@@ -357,6 +357,12 @@ def group_norm_conv3x3_wino(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Te
                      ld_res=cout if residual is not None else 0, ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, images=images, hin=h,
                      win=w_, cin1=c, cin2=0, cout=cout, stride=1, upsample=0, rows_per_group=rows_per_group, alpha=1.0, post_scale=post_scale,
                      act=ACT_NONE, out_f32=0, dtype=dt_code(x.dtype), pad_asym=0, w_wino=_p(w_wino), x_is_wino_v=1)
+    # would the convolution take the Winograd route (given enough workspace)?  ca_conv3x3_workspace_bytes alone cannot tell: it also
+    # answers > 0 for the split-K plan of a shape the route declines
+    cargs.workspace, cargs.workspace_bytes = _p(v), 1 << 60
+    buf = C.create_string_buffer(64)
+    if lib().ca_conv3x3_plan_name(C.byref(cargs), buf, 64) != 0 or not buf.value.decode().startswith("wino"):
+        return None
     wbytes = int(lib().ca_conv3x3_workspace_bytes(C.byref(cargs)))
     gargs = GroupNormArgs(x=_p(x), x2=_p(x2), y=None, gamma=_p(gamma), beta=_p(beta), partials=None, images=images, hw=h * w_, c1=c1, c2=c2,
                           groups=groups, frames_per_stat=1, eps=eps, act=act, dtype=dt_code(x.dtype), wino_v=_p(v), wino_h=h, wino_w=w_)

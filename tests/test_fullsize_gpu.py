@@ -227,3 +227,40 @@ def test_config2_step_repeats_bit_identically_with_the_controlnet_stream_beside_
     assert torch.isfinite(first).all()
     differing = sum(int(not torch.equal(step(), first)) for _ in range(8))
     assert differing == 0, f"{differing} of 8 repeats differ from the first"
+
+
+def test_config1_shape_v2_full_width_winograd_paths_agree():
+    """BASELINE config 1's shape (8 frames, 32x32 latents: levels 32, 16, 8, 4) on the full-width mm-v2 UNet3D: the 8x8- and 16x16-latent
+    convolutions take the Winograd route (with the GroupNorm writing the transformed input where it can), the 4x4 level -- 64 tiles --
+    must keep the direct split-K form.  The fused GroupNorm -> V form is bit-identical to GroupNorm + convolution; against the direct
+    convolutions the route moves eps by fp16 rounding only."""
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.configs import unet_config
+    from controlanimate_amd.context import dispatch
+    from controlanimate_amd.unet import UNet3DConditionModel
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        unet = UNet3DConditionModel.from_config(unet_config("v2"))
+    for p in unet.parameters():
+        if p.dim() > 1 and float(p.detach().abs().max()) == 0.0:
+            p.data.normal_(std=0.02)
+    unet.prepare(DEV, torch.float16)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 4, 8, 32, 32, generator=g).to(DEV)
+    ehs = (torch.randn(2, 77, 768, generator=g) * 0.5).to(DEV)
+    K._plan_sink = labels = []
+    try:
+        fused = unet(x, 500, ehs).sample
+    finally:
+        K._plan_sink = None
+    assert torch.isfinite(fused).all()
+    assert any(l == "gn_wino_pq256x320" for l in labels) and any(l == "wino_pq256x320" for l in labels), sorted(set(labels))
+    try:
+        dispatch.gn_winograd = False
+        separate = unet(x, 500, ehs).sample
+        dispatch.conv_winograd = False
+        direct = unet(x, 500, ehs).sample
+    finally:
+        dispatch.gn_winograd = dispatch.conv_winograd = True
+    assert torch.equal(fused, separate)
+    assert rel(fused, direct) < 2e-3

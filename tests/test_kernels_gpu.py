@@ -928,6 +928,18 @@ def test_conv3x3_winograd():
             rel_d = ((direct.float() - ref).norm() / ref.norm()).item()
             assert torch.isfinite(y.float()).all() and rel < 3e-3, (images, h, c1, c2, cout, epi, rel, rel_d)
             assert torch.equal(y, W.run(d, True))
+    # bf16: the transforms run in fp32 arithmetic (no packed bf16 add); the transformed operands carry 8 mantissa bits
+    for (images, h, c1, c2, cout) in [(32, 16, 1280, 0, 1280), (32, 8, 1280, 1280, 1280)]:
+        d = W.make(images, h, c1, c2, cout, dt=torch.bfloat16, epilogue=True)
+        k._plan_sink = labels = []
+        try:
+            y, direct = W.run(d, True), W.run(d, False)
+        finally:
+            k._plan_sink = None
+        assert labels[0] == "wino_pq256x320" and not labels[1].startswith("wino"), labels
+        ref = W.reference(d)
+        rel, rel_d = ((y.float() - ref).norm() / ref.norm()).item(), ((direct.float() - ref).norm() / ref.norm()).item()
+        assert torch.isfinite(y.float()).all() and rel < 1.2e-2 and rel < 5 * rel_d, (rel, rel_d)
     # Upsample3D: nearest x2 folded into the input transform (resnet.py:67-81), against F.interpolate + conv2d
     import torch.nn.functional as F
     d = W.make(32, 8, 1280, 0, 1280, epilogue=False)
@@ -987,7 +999,8 @@ def test_groupnorm_writes_the_winograd_input_transform():
         ref = W.reference(dd)
         assert ((y.float() - ref).norm() / ref.norm()).item() < 3e-3
     # declined: 60 channels per group (C = 1920) is not whole 8-channel chunks; a 32x32 image does not fit the one-launch GroupNorm
-    for (images, h, c1, c2, cout) in [(32, 16, 1280, 640, 1280), (8, 32, 1280, 0, 1280)]:
+    # ... and a 4x4 image is 64 tiles: the convolution keeps the direct (split-K) form, whose workspace must not be mistaken for the route's
+    for (images, h, c1, c2, cout) in [(32, 16, 1280, 640, 1280), (8, 32, 1280, 0, 1280), (16, 4, 1280, 0, 1280)]:
         d = W.make(images, h, c1, c2, cout, epilogue=False)
         gamma, beta = torch.ones(c1 + c2, device=DEV), torch.zeros(c1 + c2, device=DEV)
         assert k.group_norm_conv3x3_wino(d["x"], gamma, beta, d["w"], d["u"], x2=d["x2"], act=k.ACT_SILU) is None
