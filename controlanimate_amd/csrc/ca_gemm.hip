@@ -960,8 +960,12 @@ static int64_t wino_workspace_bytes(const ca_conv_args* a) {
   const int h = a->hin << a->upsample, w = a->win << a->upsample;  // logical input = output size
   if (a->images <= 0 || h < 2 || w < 2 || (h & 1) || (w & 1)) return 0;
   const int kc = a->cin1 + a->cin2;
-  if (kc < 1280 || kc % BK != 0 || a->cin1 % 8 != 0 || a->cin2 % 8 != 0 || a->cout % 320 != 0) return 0;
+  static const int min_cin = CA_KNOB("CA_WINO_MIN_CIN", 1280);  // (experiments: where the route stops paying)
+  if (kc < 640 || kc % BK != 0 || a->cin1 % 8 != 0 || a->cin2 % 8 != 0 || a->cout % 320 != 0) return 0;
   const int64_t tiles = (int64_t)a->images * (h / 2) * (w / 2);
+  // input channels: >= 1280 everywhere in the window; 640 .. 1279 only at <= 4096 tiles, where the direct form is short of tiles
+  // (32 x 16x16 640->1280: 100 vs 160 us; at 8192 tiles 640->640 254 vs 233-252, 960->640 318 vs 331: no / marginal gain)
+  if (kc < min_cin && !(min_cin == 1280 && tiles <= 4096)) return 0;
   // whole 256-row tiles per transformed GEMM.  Measured (tools/wino_check.py, us, Winograd vs direct): 32 x 16x16 1280->1280 170 vs 276,
   // 2560->1280 285 vs 529, 32 x 8x8 1280->1280 66 vs 87, 32 x 32x32 1920->640 510 vs 584, 1280->1280 634 vs 800; with 640 input channels
   // the sixteen K = 640 GEMMs are epilogue-bound and the 4 x larger V / M tensors cost more than the saved MFMAs (no gain): >= 1280 only

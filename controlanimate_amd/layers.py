@@ -223,7 +223,7 @@ class HipConv3x3(nn.Module):
         self.b = arena.add((self.out_channels,), torch.float32, lambda: _f32(self.bias))
         # the deep stride-1 convolutions also in Winograd form: ca_conv3x3 takes it at the small-latent levels (ca_conv_args.w_wino, ABI v12)
         self.u = None
-        if (dispatch.conv_winograd and self.stride == 1 and self.winograd and self.in_channels >= 1280 and self.in_channels % 64 == 0
+        if (dispatch.conv_winograd and self.stride == 1 and self.winograd and self.in_channels >= 640 and self.in_channels % 64 == 0
                 and self.out_channels % 320 == 0):
             self.u = arena.add((16, self.out_channels, self.in_channels), dtype, self._winograd_weight)
 

@@ -313,8 +313,8 @@ typedef struct ca_conv_args {
   int32_t pad_asym;
   /* ABI v12: the weight once more in Winograd form, U [16][cout][cin1 + cin2] = G g G^T per (cout, cin) (written by ca_pack_w_wino
    * from `w`), or NULL.  With it -- and a workspace of ca_conv3x3_workspace_bytes(args) bytes -- the deep convolutions of the small-latent
-   * levels (stride 1, padding 1, with or without `upsample`, even output H and W, cin >= 1280, cout % 320 == 0, images * Hout * Wout / 4
-   * a multiple of 256 and at most 16384 tiles) run as F(2x2, 3x3): an input transform, ONE launch of the 256 x 320 GEMM kernel over the sixteen transformed GEMMs,
+   * levels (stride 1, padding 1, with or without `upsample`, even output H and W, cin >= 1280 (>= 640 at up to 4096 tiles), cout % 320 == 0,
+   * images * Hout * Wout / 4 a multiple of 256 and at most 16384 tiles) run as F(2x2, 3x3): an input transform, ONE launch of the 256 x 320 GEMM kernel over the sixteen transformed GEMMs,
    * an output transform that applies the epilogue.  2.25 x fewer multiply-adds; results differ from the direct form by fp16 rounding
    * of the transformed operands (tests/test_kernels_gpu.py::test_conv3x3_winograd).  NULL / no workspace / another shape: the direct form. */
   const void* w_wino;

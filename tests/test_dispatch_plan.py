@@ -335,7 +335,9 @@ def test_winograd_route_of_the_deep_small_latent_convolutions(capi):
     assert label(32, 32, 1280, 1280)[0] == "wino_pq256x320"             # 8192 tiles: 634 vs 800 us (tools/wino_check.py)
     assert label(32, 16, 1280, 1280, upsample=1)[0] == "wino_pq256x320"  # Upsample3D: the nearest x2 folded into the input transform
     assert not label(64, 64, 1280, 1280)[0].startswith("wino")          # 65536 tiles: beyond the window
-    assert not label(32, 16, 640, 1280)[0].startswith("wino")           # shallow input: sixteen K = 640 GEMMs are epilogue-bound
+    assert label(32, 16, 640, 1280)[0] == "wino_pq256x320"              # 640 input channels pay at <= 4096 tiles (100 vs 160 us) ...
+    assert not label(32, 32, 640, 640)[0].startswith("wino")            # ... not at 8192 (254 vs 233-252: sixteen K = 640 GEMMs are epilogue-bound)
+    assert not label(32, 16, 320, 640)[0].startswith("wino")
     assert not label(32, 16, 1280, 1280, stride=2)[0].startswith("wino")
     assert not label(32, 3, 1280, 1280, upsample=1)[0].startswith("wino")  # 6 x 6 logical: 288 tiles, not whole 256-row GEMM tiles
     assert label(32, 16, 1280, 1280, dtype=capi.CA_BF16)[0] == "wino_pq256x320"   # (bf16: the transforms in fp32 arithmetic)

@@ -263,4 +263,6 @@ def test_config1_shape_v2_full_width_winograd_paths_agree():
     finally:
         dispatch.gn_winograd = dispatch.conv_winograd = True
     assert torch.equal(fused, separate)
-    assert rel(fused, direct) < 2e-3
+    # (two fp16 paths whose rounding errors are independent: each sits 1.4e-3 .. 2.4e-3 from the fp32 oracle -- tools/bf16_fullwidth_gpu.py --
+    #  so their distance is of that order; a wrong transform would be off by O(1))
+    assert rel(fused, direct) < 5e-3

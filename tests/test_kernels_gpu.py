@@ -913,7 +913,7 @@ def test_conv3x3_winograd():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import wino_check as W
     k = _k()
-    for (images, h, c1, c2, cout) in [(32, 16, 1280, 0, 1280), (32, 16, 1280, 640, 1280), (32, 8, 1280, 1280, 1280), (16, 16, 1280, 640, 640)]:
+    for (images, h, c1, c2, cout) in [(32, 16, 1280, 0, 1280), (32, 16, 1280, 640, 1280), (32, 8, 1280, 1280, 1280), (16, 16, 1280, 640, 640), (32, 16, 640, 0, 1280)]:
         for epi in (True, False):
             d = W.make(images, h, c1, c2, cout, epilogue=epi)
             k._plan_sink = labels = []
@@ -954,8 +954,8 @@ def test_conv3x3_winograd():
     ref = F.conv2d(up, d["w"].float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
     assert tuple(y.shape) == (32, 16, 16, 1280)
     assert ((y.float() - ref).norm() / ref.norm()).item() < 3e-3 and ((direct.float() - ref).norm() / ref.norm()).item() < 3e-3
-    # outside the window: a shallow input -> the direct kernels, whatever w_wino says
-    d = W.make(32, 16, 640, 0, 640, epilogue=False)
+    # outside the window: 640 input channels at 8192 tiles -> the direct kernels, whatever w_wino says
+    d = W.make(32, 32, 640, 0, 640, epilogue=False)
     k._plan_sink = labels = []
     try:
         W.run(d, True)

@@ -96,7 +96,10 @@ def timeit(fn):
 
 
 def timing():
-    for (images, h, c1, c2, cout) in SHAPES + [(32, 32, 1280, 640, 640), (32, 32, 640, 640, 640), (32, 32, 1280, 0, 1280), (32, 16, 640, 0, 1280)]:
+    extra = [(32, 32, 1280, 640, 640), (32, 32, 640, 640, 640), (32, 32, 1280, 0, 1280), (32, 16, 640, 0, 1280)]
+    if "--shallow" in sys.argv:  # (experiments build, CA_WINO_MIN_CIN=320 CA_WINO_MAX_TILES=32768: where does the route stop paying?)
+        extra = [(32, 32, 640, 0, 640), (32, 32, 640, 320, 640), (32, 16, 640, 0, 1280), (32, 64, 320, 0, 320), (32, 64, 640, 320, 320), (32, 64, 320, 320, 320)]
+    for (images, h, c1, c2, cout) in (extra if "--shallow" in sys.argv else SHAPES + extra):
         d = make(images, h, c1, c2, cout)
         d["post"] = 1.0  # (the resnets' output_scale_factor: the 256 x 320 direct kernel has no post scale)
         K._plan_sink = labels = []
