@@ -52,10 +52,13 @@ struct AttnOutRegs {
   u32x2 r4[4];
 };
 
-// row_base: byte-less ROW index of this lane's row in row tile 0 of the wave's half; row tile i of the half is row_base + i * row_step.
+// row_base: ROW index (not bytes) of this lane's row in row tile 0 of the wave's half; row tile i of the half is the row
+// row_base + (i & 1) * step_a + (i >> 1) * step_b  (consecutive rows: 16, 32; the temporal kernels' (pixel, frame) tiles: see their callers).
+__device__ __forceinline__ unsigned attn_out_row(unsigned row_base, unsigned step_a, unsigned step_b, int i) { return row_base + (unsigned)(i & 1) * step_a + (unsigned)(i >> 1) * step_b; }
+
 template <int DT>
 __device__ __forceinline__ void attn_out_prefetch(AttnOutRegs& R, const AttnOutParams& a, __amdgpu_buffer_rsrc_t rs_wo, __amdgpu_buffer_rsrc_t rs_res, int wid,
-                                                  int lane, unsigned row_base, unsigned row_step) {
+                                                  int lane, unsigned row_base, unsigned step_a, unsigned step_b) {
   const int cg = wid & 3, g = lane >> 4;
   const unsigned wv = (unsigned)lane * 16u;
   const unsigned wbase = (unsigned)cg * (10u * 5u * 1024u);
@@ -65,7 +68,7 @@ __device__ __forceinline__ void attn_out_prefetch(AttnOutRegs& R, const AttnOutP
     for (int j = 0; j < 5; ++j) R.fb[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wo, wv, wbase + (unsigned)(c * 5 + j) * 1024u, 0));
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const unsigned ro = (row_base + (unsigned)i * row_step) * (unsigned)a.ld_res * 2u + (unsigned)(cg * 80) * 2u;  // (size-0 descriptor without a residual: zeros)
+    const unsigned ro = attn_out_row(row_base, step_a, step_b, i) * (unsigned)a.ld_res * 2u + (unsigned)(cg * 80) * 2u;  // (size-0 descriptor without a residual: zeros)
     R.rr[i][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro + (unsigned)(8 * g) * 2u, 0, 0));
     R.rr[i][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro + (unsigned)(32 + 8 * g) * 2u, 0, 0));
     R.r4[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, ro + (unsigned)(64 + 4 * g) * 2u, 0, 0));
@@ -86,7 +89,7 @@ __device__ __forceinline__ unsigned attn_out_add(unsigned w, unsigned r_) {
 template <int DT>
 __device__ __forceinline__ void attn_out_run(AttnOutRegs& R, const unsigned char* tile, const int (&fa_b)[2][2], const AttnOutParams& a,
                                              __amdgpu_buffer_rsrc_t rs_wo, __amdgpu_buffer_rsrc_t rs_bo, __amdgpu_buffer_rsrc_t rs_y, int wid, int lane,
-                                             unsigned row_base, unsigned row_step, unsigned ldo) {
+                                             unsigned row_base, unsigned step_a, unsigned step_b, unsigned ldo) {
   constexpr int KQ = 10, ROWB = 640;
   const int rh = wid >> 2, cg = wid & 3;
   int lane_k = lane;
@@ -149,7 +152,7 @@ __device__ __forceinline__ void attn_out_run(AttnOutRegs& R, const unsigned char
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const unsigned ro = (row_base + (unsigned)i * row_step) * ldo * 2u + (unsigned)(cg * 80) * 2u;
+    const unsigned ro = attn_out_row(row_base, step_a, step_b, i) * ldo * 2u + (unsigned)(cg * 80) * 2u;
     __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][0], w[i][1], w[i][2], w[i][3]}, rs_y, ro + (unsigned)(8 * g) * 2u, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[i][4], w[i][5], w[i][6], w[i][7]}, rs_y, ro + (unsigned)(32 + 8 * g) * 2u, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b64((u32x2){w[i][8], w[i][9]}, rs_y, ro + (unsigned)(64 + 4 * g) * 2u, 0, 0);

@@ -285,10 +285,10 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
         asm volatile("" : "+v"(lane_e));
         const unsigned row_base = (unsigned)(m0 + (lane_e & 15));
         AttnOutRegs R;
-        attn_out_prefetch<DT>(R, p.out, rs_wo, rs_ro, wid, lane_e, row_base, 16u);
+        attn_out_prefetch<DT>(R, p.out, rs_wo, rs_ro, wid, lane_e, row_base, 16u, 32u);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // the y tile is complete
-        attn_out_run<DT>(R, smem, fa_b, p.out, rs_wo, rs_bo, rs_y, wid, lane_e, row_base, 16u, (unsigned)p.ldc);
+        attn_out_run<DT>(R, smem, fa_b, p.out, rs_wo, rs_bo, rs_y, wid, lane_e, row_base, 16u, 32u, (unsigned)p.ldc);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave has read the y tile: the next x tile may land
         if (tile + (int)gridDim.x < tiles_m) x_tile_dma(tile + gridDim.x);
@@ -397,10 +397,10 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfParams p, int tiles_m) {
           ca_lds_store8(rowp + (((c2 >> 3) ^ fs) << 4) + (c2 & 7) * 2, (u32x2){w[i][8], w[i][9]});
         }
         AttnOutRegs R;
-        attn_out_prefetch<DT>(R, p.out, rs_wo, rs_ro, wid, lane_e, row_base, 16u);
+        attn_out_prefetch<DT>(R, p.out, rs_wo, rs_ro, wid, lane_e, row_base, 16u, 32u);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // the y tile is complete (matches the producers' barrier)
-        attn_out_run<DT>(R, smem, fa_b, p.out, rs_wo, rs_bo, rs_y, wid, lane_e, row_base, 16u, (unsigned)p.ldc);
+        attn_out_run<DT>(R, smem, fa_b, p.out, rs_wo, rs_bo, rs_y, wid, lane_e, row_base, 16u, 32u, (unsigned)p.ldc);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave has read the y tile
       } else {

@@ -154,7 +154,13 @@ extern "C" int ca_pack_w_out(const void* w, int32_t n, int32_t k, void* dst, voi
 
 extern "C" int ca_tattn_fused_supported(const ca_tattn_args* a) {
   if (!a || !a->x || !a->w_frag || !a->gamma || !a->bias_pe || !a->o) return 0;
-  if (a->c != 320 || a->heads != 8 || a->frames != 16 || a->batch < 1 || a->tokens < 8 || a->tokens % 8) return 0;
+  if (a->c != 320 || a->heads != 8 || a->batch < 1) return 0;
+  // 16 frames: both forms; 8 / 32 frames (ABI v12): the eight-wave kernel only, i.e. with the output stage
+  if (a->frames != 16 && !((a->frames == 8 || a->frames == 32) && a->w_out_frag)) return 0;
+  {
+    const int px = 128 / a->frames;  // pixels per 128-row tile
+    if (a->tokens < px || a->tokens % px) return 0;
+  }
   if (a->dtype != CA_BF16 && a->dtype != CA_F16) return 0;
   const int64_t rows = (int64_t)a->batch * a->frames * a->tokens;
   if (rows < 16384) return 0;
@@ -184,7 +190,7 @@ extern "C" int ca_tattn_fused(const ca_tattn_args* a, void* stream) {
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.x_bytes = (unsigned)(((rows - 1) * a->lda + 320) * 2);
   p.o_bytes = (unsigned)(((rows - 1) * a->ldo + 320) * 2);
-  const int tiles = (int)((int64_t)a->batch * a->tokens / 8);
+  const int tiles = (int)((int64_t)a->batch * a->tokens / (128 / a->frames));
   static const int dbg = CA_KNOB("CA_TATTN_DBG", 0);
   p.dbg = dbg;
   if (a->w_out_frag) {  // with the output projection: one block of eight waves per CU (k_tattn_out)
@@ -194,8 +200,13 @@ extern "C" int ca_tattn_fused(const ca_tattn_args* a, void* stream) {
     p.out.ld_res = (int)a->ld_res;
     p.out.res_bytes = a->residual ? (unsigned)(((rows - 1) * a->ld_res + 320) * 2) : 0u;
     const unsigned grid1 = (unsigned)(tiles < ar_cu_count() ? tiles : ar_cu_count());
-    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_tattn_out<CA_BF16>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
-    else hipLaunchKernelGGL((k_tattn_out<CA_F16>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+#define CA_TATTN_OUT(FR)                                                                                                              \
+  if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_tattn_out<CA_BF16, FR>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles); \
+  else hipLaunchKernelGGL((k_tattn_out<CA_F16, FR>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+    if (a->frames == 8) { CA_TATTN_OUT(8) }
+    else if (a->frames == 32) { CA_TATTN_OUT(32) }
+    else { CA_TATTN_OUT(16) }
+#undef CA_TATTN_OUT
     CA_CHECK_LAUNCH("ca_tattn_fused(out)");
     return CA_OK;
   }

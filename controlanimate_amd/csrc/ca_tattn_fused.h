@@ -303,8 +303,12 @@ __global__ __launch_bounds__(256, 2) void k_tattn_fused(TattnParams p, int tiles
 //   o       o -> buf[t & 1] in place of x' (8-byte pieces, the tile's swizzle)                    barrier
 //   out     y = o Wout^T + b + residual, 64 x 80 per wave (ca_attn_out.h), stores
 // o never reaches HBM (84 MB written + read per launch) and the k_gemm_wres launch behind it is gone.
-template <int DT>
+// FR = frames per sequence: 16 (one MFMA row tile per pixel, 8 pixels per tile), 32 (two row tiles per pixel, 4 pixels: S^T and
+// O^T in 2 x 2 / 2 blocks of 16 x 16) or 8 (two pixels per row tile, 16 pixels: the cross-pixel quarter of S^T masked out).
+template <int DT, int FR>
 __global__ __launch_bounds__(512, 2) void k_tattn_out(TattnParams p, int tiles) {
+  static_assert(FR == 8 || FR == 16 || FR == 32, "frames per sequence");
+  constexpr int PXT = 128 / FR;  // pixels per 128-row tile; LDS row = FR * pixel + frame
   constexpr int K = 320, KQ = 10, TM = 8, TJ = 3, BM = 128, HD = 40;
   constexpr int ROWB = K * 2, TILEB = BM * ROWB;
   constexpr unsigned CHUNKB = TJ * 1024u;
@@ -331,17 +335,17 @@ __global__ __launch_bounds__(512, 2) void k_tattn_out(TattnParams p, int tiles) 
   // tile DMA by waves 0..3, 20 wave instructions (1 KB of the tile image) each
   auto issue_tile = [&](int tile, int bufsel) __attribute__((always_inline)) {
     if (wid >= 4) return;
-    const int g0 = tile * 8;
+    const int g0 = tile * PXT;
     const int bimg = g0 / p.hw, pix0 = g0 - bimg * p.hw;
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));
 #pragma unroll
     for (int q = 0; q < 20; ++q) {
       const unsigned idx = (unsigned)((wid * 20 + q) * 64 + lane_o);
-      const unsigned r = __umulhi(idx >> 3, 0xCCCCCCCDu) >> 2;  // idx / 40: LDS row = 16 * pixel + frame
+      const unsigned r = __umulhi(idx >> 3, 0xCCCCCCCDu) >> 2;  // idx / 40: LDS row = FR * pixel + frame
       const unsigned cp = idx - r * 40u;
       const unsigned c = cp ^ ((r >> 1) & 7u);
-      const unsigned grow = (unsigned)((bimg * 16 + (int)(r & 15u)) * p.hw + pix0) + (r >> 4);
+      const unsigned grow = (unsigned)((bimg * FR + (int)(r & (unsigned)(FR - 1))) * p.hw + pix0) + r / (unsigned)FR;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + bufsel * TILEB + (wid * 20 + q) * 1024), 16,
                                                grow * (unsigned)p.lda * 2u + c * 16u, 0, 0, 0);
     }
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void k_tattn_out(TattnParams p, int tiles) 
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x, ++it) {
     const int cur = it & 1;
     unsigned char* const xb = smem + cur * TILEB;
-    const int g0 = tile * 8;
+    const int g0 = tile * PXT;
     const int bimg = g0 / p.hw, pix0 = g0 - bimg * p.hw;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // x(tile) has landed; every wave is past the previous tile's output stage
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void k_tattn_out(TattnParams p, int tiles) 
       const int r = tid >> 2, h = tid & 3;
       const int fs = (r >> 1) & 7;
       unsigned char* src = xb + r * ROWB + h * 160;
-      const float* bprow = p.bp + (int64_t)(r & 15) * p.ld_bp;
+      const float* bprow = p.bp + (int64_t)(r & (FR - 1)) * p.ld_bp;
       float s = 0.f, ss = 0.f;
 #pragma unroll 5
       for (int q = 0; q < 10; ++q) {
@@ -454,46 +458,109 @@ __global__ __launch_bounds__(512, 2) void k_tattn_out(TattnParams p, int tiles) 
         for (int j = 0; j < TJ; ++j)
           qp[i][j] = (u32x2){pack2<DT>(acc[i][j][0] * p.scale_log2, acc[i][j][1] * p.scale_log2), pack2<DT>(acc[i][j][2] * p.scale_log2, acc[i][j][3] * p.scale_log2)};
     }
-    u32x2 pp[TM];
+    // P^T as the B operand of O^T = V^T P^T.  FR <= 16: pp[i][0] for row tile i; FR = 32: pp[2 px + kt][qt] for the (key tile, query tile) block
+    u32x2 pp[TM][FR == 32 ? 2 : 1];
     {
       f32x4 acc[TM][TJ];
       kloop(IntC<1>{}, acc);
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
+      const int l15s = lane_s & 15, gs = lane_s >> 4;
+      if constexpr (FR != 32) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        f32x4 st = {0.f, 0.f, 0.f, 0.f};  // S^T[key = 4 g + r][query = l15] in the exp2 domain
+        for (int i = 0; i < TM; ++i) {
+          f32x4 st = {0.f, 0.f, 0.f, 0.f};  // S^T[key = 4 g + r][query = l15] in the exp2 domain
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          const u32x2 kp = {pack2<DT>(acc[i][j][0], acc[i][j][1]), pack2<DT>(acc[i][j][2], acc[i][j][3])};
-          st = Elem<DT>::mfma16(kp, qp[i][j], st);
+          for (int j = 0; j < TJ; ++j) {
+            const u32x2 kp = {pack2<DT>(acc[i][j][0], acc[i][j][1]), pack2<DT>(acc[i][j][2], acc[i][j][3])};
+            st = Elem<DT>::mfma16(kp, qp[i][j], st);
+          }
+          if constexpr (FR == 8) {  // two pixels share the row tile: a key of the other pixel is not a key
+            if ((gs >> 1) != (l15s >> 3)) st = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          }
+          const float m = rowgroup_max(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
+          float e[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(st[r] - m);
+          const float inv = __builtin_amdgcn_rcpf(rowgroup_sum((e[0] + e[1]) + (e[2] + e[3])));
+          pp[i][0] = (u32x2){pack2<DT>(e[0] * inv, e[1] * inv), pack2<DT>(e[2] * inv, e[3] * inv)};
         }
-        const float m = rowgroup_max(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
-        float e[4];
+      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(st[r] - m);
-        const float inv = __builtin_amdgcn_rcpf(rowgroup_sum((e[0] + e[1]) + (e[2] + e[3])));
-        pp[i] = (u32x2){pack2<DT>(e[0] * inv, e[1] * inv), pack2<DT>(e[2] * inv, e[3] * inv)};
+        for (int px = 0; px < 4; ++px) {
+          u32x2 kp[2][TJ];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+              kp[kt][j] = (u32x2){pack2<DT>(acc[2 * px + kt][j][0], acc[2 * px + kt][j][1]), pack2<DT>(acc[2 * px + kt][j][2], acc[2 * px + kt][j][3])};
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {  // queries: frames 16 qt + l15; keys: frames 16 kt + 4 g + r
+            f32x4 st[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int j = 0; j < TJ; ++j) st[kt] = Elem<DT>::mfma16(kp[kt][j], qp[2 * px + qt][j], st[kt]);
+            }
+            const float m = rowgroup_max(fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])), fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3]))));
+            float e[2][4], l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                e[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - m);
+                l += e[kt][r];
+              }
+            const float inv = __builtin_amdgcn_rcpf(rowgroup_sum(l));
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) pp[2 * px + kt][qt] = (u32x2){pack2<DT>(e[kt][0] * inv, e[kt][1] * inv), pack2<DT>(e[kt][2] * inv, e[kt][3] * inv)};
+          }
+        }
       }
     }
-    u32x2 op[TM][TJ];  // O^T[d_v = 16 j + 4 g + r][query = frame l15] of pixel i, rounded to the activation type
+    u32x2 op[TM][TJ];  // O^T[d_v = 16 j + 4 g + r][query = frame] of row tile i, rounded to the activation type
     {
       f32x4 acc[TM][TJ];
       kloop(IntC<2>{}, acc);
+      if constexpr (FR != 32) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          const u32x2 vp = {pack2<DT>(acc[i][j][0], acc[i][j][1]), pack2<DT>(acc[i][j][2], acc[i][j][3])};
-          const f32x4 ot = Elem<DT>::mfma16(vp, pp[i], (f32x4){0.f, 0.f, 0.f, 0.f});
-          op[i][j] = (u32x2){pack2<DT>(ot[0], ot[1]), pack2<DT>(ot[2], ot[3])};
-        }
+          for (int j = 0; j < TJ; ++j) {
+            const u32x2 vp = {pack2<DT>(acc[i][j][0], acc[i][j][1]), pack2<DT>(acc[i][j][2], acc[i][j][3])};
+            const f32x4 ot = Elem<DT>::mfma16(vp, pp[i][0], (f32x4){0.f, 0.f, 0.f, 0.f});
+            op[i][j] = (u32x2){pack2<DT>(ot[0], ot[1]), pack2<DT>(ot[2], ot[3])};
+          }
+      } else {
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            u32x2 vp[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) vp[kt] = (u32x2){pack2<DT>(acc[2 * px + kt][j][0], acc[2 * px + kt][j][1]), pack2<DT>(acc[2 * px + kt][j][2], acc[2 * px + kt][j][3])};
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+              f32x4 ot = Elem<DT>::mfma16(vp[0], pp[2 * px][qt], (f32x4){0.f, 0.f, 0.f, 0.f});
+              ot = Elem<DT>::mfma16(vp[1], pp[2 * px + 1][qt], ot);
+              op[2 * px + qt][j] = (u32x2){pack2<DT>(ot[0], ot[1]), pack2<DT>(ot[2], ot[3])};
+            }
+          }
+      }
     }
     // output stage: its first W chunks and the residual rows are requested before the barriers
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int l15e = lane_e & 15, ge = lane_e >> 4;
-    const unsigned row_base = (unsigned)((bimg * 16 + l15e) * p.hw + pix0) + (unsigned)((wid >> 2) * 4);  // pixel 4 rh + i of frame l15: rows one apart
+    // global row of LDS row 64 rh + 16 i + l15 (= FR * pixel + frame) = row_base + (i & 1) * step_a + (i >> 1) * step_b:
+    //   FR 16: pixel 4 rh + i, frame l15;  FR 32: pixel 2 rh + (i >> 1), frame 16 (i & 1) + l15;  FR 8: pixel 8 rh + 2 i + (l15 >> 3), frame l15 & 7
+    const int rh_ = wid >> 2;
+    const unsigned row_base = FR == 16 ? (unsigned)((bimg * 16 + l15e) * p.hw + pix0 + 4 * rh_)
+                                       : FR == 32 ? (unsigned)((bimg * 32 + l15e) * p.hw + pix0 + 2 * rh_) : (unsigned)((bimg * 8 + (l15e & 7)) * p.hw + pix0 + 8 * rh_ + (l15e >> 3));
+    const unsigned step_a = FR == 16 ? 1u : FR == 32 ? 16u * (unsigned)p.hw : 2u, step_b = FR == 16 ? 2u : FR == 32 ? 1u : 4u;
     AttnOutRegs R;
-    attn_out_prefetch<DT>(R, p.out, rs_wo, rs_res, wid, lane_e, row_base, 1u);
+    attn_out_prefetch<DT>(R, p.out, rs_wo, rs_res, wid, lane_e, row_base, step_a, step_b);
     __syncthreads();  // every wave has finished its K loops on x'
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -507,6 +574,6 @@ __global__ __launch_bounds__(512, 2) void k_tattn_out(TattnParams p, int tiles) 
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // the o tile is complete
-    attn_out_run<DT>(R, xb, fa_b, p.out, rs_wo, rs_bo, rs_o, wid, lane_e, row_base, 1u, (unsigned)p.ldo);
+    attn_out_run<DT>(R, xb, fa_b, p.out, rs_wo, rs_bo, rs_o, wid, lane_e, row_base, step_a, step_b, (unsigned)p.ldo);
   }
 }

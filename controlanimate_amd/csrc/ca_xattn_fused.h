@@ -481,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) 
     const int l15e = lane_e & 15, ge = lane_e >> 4;
     const unsigned row_base = (unsigned)(m0 + (wid >> 2) * 64 + l15e);
     AttnOutRegs R;
-    attn_out_prefetch<DT>(R, p.out, rs_wo, rs_res, wid, lane_e, row_base, 16u);
+    attn_out_prefetch<DT>(R, p.out, rs_wo, rs_res, wid, lane_e, row_base, 16u, 32u);
     __syncthreads();  // every wave has finished its K loop on the normalised tile
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -495,6 +495,6 @@ __global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) 
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // the o tile is complete
-    attn_out_run<DT>(R, xb, fa_b, p.out, rs_wo, rs_bo, rs_o, wid, lane_e, row_base, 16u, (unsigned)p.ldo);
+    attn_out_run<DT>(R, xb, fa_b, p.out, rs_wo, rs_bo, rs_o, wid, lane_e, row_base, 16u, 32u, (unsigned)p.ldo);
   }
 }

@@ -177,8 +177,8 @@ int ca_pack_w2_frag(const void* w, int32_t n, int32_t k, void* dst, void* stream
 /* ABI v10: the motion module's temporal self-attention of the 64x64-latent level up to (not including) its output projection,
  *   o = softmax(q k^T * scale) v per (pixel, head) over the frames,  q | k | v = (LayerNorm(x) + pe[frame]) Wqkv^T,
  * in one launch (animatediff/models/motion_module.py:251-331: norm, pos_encoder, to_q / to_k / to_v, attention with the frames
- * as the sequence).  Rows of x and o are in (batch, frame, token) order.  Takes c = 320, 8 heads, 16 frames, tokens % 8 == 0,
- * >= 16384 rows (ca_tattn_fused_supported: no launch, no device access); everything else runs as ca_gemm + ca_attention.
+ * as the sequence).  Rows of x and o are in (batch, frame, token) order.  Takes c = 320, 8 heads, 16 frames (ABI v12: also 8 and 32
+ * frames when the output stage is used), tokens a multiple of 128 / frames, >= 16384 rows (ca_tattn_fused_supported: no launch, no device access); everything else runs as ca_gemm + ca_attention.
  *   w_frag: CA_TATTN_W_FRAG_ELEMS 16-bit elements in the order of ca_pack_w_tattn (the UNFOLDED Wq | Wk | Wv);
  *   gamma [c] fp32: the LayerNorm weight; bias_pe [frames][ld_bias_pe] fp32: LayerNorm bias + positional encoding of the frame. */
 #define CA_TATTN_W_FRAG_ELEMS 368640

@@ -228,6 +228,11 @@ def test_fused_temporal_attention_only_takes_what_it_implements(capi):
 
     assert ok() == 1 and ok(dtype=capi.CA_BF16) == 1 and ok(batch=1, tokens=1024) == 1 and ok(lda=640, tokens=6144) == 1
     assert ok(frames=8) == 0 and ok(frames=32) == 0 and ok(heads=4) == 0 and ok(c=640) == 0 and ok(tokens=4100) == 0
+    # ABI v12: 8 and 32 frames with the output stage (the eight-wave kernel); tokens in whole tiles of 128 / frames pixels; 24 frames never
+    assert ok(frames=8, w_out_frag=FAKE) == 1 and ok(frames=32, w_out_frag=FAKE, tokens=9216) == 1 and ok(frames=16, w_out_frag=FAKE, residual=FAKE, ld_res=320) == 1
+    assert ok(frames=24, w_out_frag=FAKE) == 0 and ok(frames=8, w_out_frag=FAKE, tokens=4104) == 0 and ok(frames=32, w_out_frag=FAKE, tokens=4098) == 0
+    assert ok(residual=FAKE, ld_res=320) == 0                      # a residual belongs to the output projection
+    assert ok(w_out_frag=FAKE, residual=FAKE, ld_res=324) == 0
     assert ok(batch=1, tokens=64) == 0  # 1024 rows: not worth a launch of 512 blocks
     assert ok(w_frag=None) == 0 and ok(gamma=None) == 0 and ok(bias_pe=None) == 0 and ok(x=FAKE + 8) == 0
     assert ok(lda=324) == 0 and ok(ld_bias_pe=318) == 0 and ok(ln_eps=0.0) == 0 and ok(scale=0.0) == 0 and ok(dtype=7) == 0

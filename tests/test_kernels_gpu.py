@@ -1004,3 +1004,41 @@ def test_groupnorm_writes_the_winograd_input_transform():
         d = W.make(images, h, c1, c2, cout, epilogue=False)
         gamma, beta = torch.ones(c1 + c2, device=DEV), torch.zeros(c1 + c2, device=DEV)
         assert k.group_norm_conv3x3_wino(d["x"], gamma, beta, d["w"], d["u"], x2=d["x2"], act=k.ACT_SILU) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fr", [8, 32])
+def test_tattn_fused_with_output_projection_other_frame_counts(fr):
+    """ca_tattn_fused with the output stage for 8 frames (BASELINE config 1: two pixels per MFMA row tile, the cross-pixel quarter of the
+    scores masked) and 32 frames (config 5: two row tiles per pixel, 2 x 2 score blocks) -- against fp32 torch (motion_module.py:251-331,
+    212-224) and against the unfused path (folded q|k|v GEMM, attention over the frames, output projection)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import tattn_check as T
+    from controlanimate_amd import kernels as K
+    dt = torch.float16
+    for (b, tokens, lda, res) in [(2, 4096 * 16 // fr // 2, 320, True), (1, 2048 + 128 // fr * 3, 640, True), (2, 2048, 320, False)]:
+        x, w, gamma, beta, pe = T.make(b, tokens, dt, lda=lda, fr=fr)
+        wo, bo = T.make_out(dt)
+        ref = T.reference(x, w, gamma, beta, pe, b, tokens, fr=fr) @ wo.float().t() + bo[None, :] + (x.float() if res else 0.0)
+        K._plan_sink = labels = []
+        try:
+            y = T.fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, residual=res, fr=fr)
+        finally:
+            K._plan_sink = None
+        assert y is not None and labels == ["tattn_out128"], (labels, b, tokens)
+        assert torch.equal(y, T.fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, residual=res, fr=fr))
+        rel = ((y.float() - ref).norm() / ref.norm()).item()
+        assert torch.isfinite(y.float()).all() and rel < 2e-3, (fr, b, tokens, rel)
+        # the unfused path on the same operands: folded q|k|v GEMM + attention_temporal + to_out
+        xc = x.contiguous()
+        wf = (w.float() * gamma[None, :]).to(dt)
+        qkv = K.gemm(xc, wf, bias=(w.float() @ beta).contiguous(), ln=(K.RowStats(xc, 1e-5), wf.float().sum(1).contiguous()),
+                     rowbias=(pe[:fr] @ w.float().t()).repeat(b, 1).contiguous(), rows_per_group=tokens)
+        old = K.gemm(K.attention_temporal(qkv, b, fr, tokens, 8), wo, bias=bo, residual=xc if res else None)
+        rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+        assert rel < 1.5 * rel_old + 1e-4, (rel, rel_old)
+    # without the output stage only 16 frames are taken (the four-wave kernel)
+    x, w, gamma, beta, pe = T.make(2, 2048, dt, fr=fr)
+    from controlanimate_amd.layers import frag_order_tattn
+    assert K.tattn_fused(x, frag_order_tattn(w.float()).to(dt), gamma.contiguous(), (pe + beta[None, :]).contiguous(), 2, fr, 2048, 8, 1e-5, 40 ** -0.5) is None

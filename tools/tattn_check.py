@@ -17,30 +17,30 @@ dev = "cuda"
 HEADS, D, CH, FR = 8, 40, 320, 16
 
 
-def make(b, tokens, dt, seed=3, lda=CH):
+def make(b, tokens, dt, seed=3, lda=CH, fr=FR):
     g = torch.Generator(device="cpu").manual_seed(seed)
     rn = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev)
-    rows = b * FR * tokens
+    rows = b * fr * tokens
     xw = (rn(rows, lda) * 1.5 + 0.3).to(dt)
     x = xw[:, :CH]
     w = rn(3 * CH, CH, scale=CH ** -0.5 * 2.0).to(dt)
     gamma, beta = 1.0 + 0.2 * rn(CH), 0.1 * rn(CH)
-    pos = torch.arange(24).unsqueeze(1)
+    pos = torch.arange(32).unsqueeze(1)
     div = torch.exp(torch.arange(0, CH, 2) * (-math.log(10000.0) / CH))
-    pe = torch.zeros(24, CH)
+    pe = torch.zeros(32, CH)
     pe[:, 0::2], pe[:, 1::2] = torch.sin(pos * div), torch.cos(pos * div)
     return x, w, gamma, beta, pe.to(dev)
 
 
-def reference(x, w, gamma, beta, pe, b, tokens):
+def reference(x, w, gamma, beta, pe, b, tokens, fr=FR):
     """fp32 throughout (rounding only where the inputs already are rounded)."""
     xf = x.float()
     n = F.layer_norm(xf, (CH,), gamma, beta, 1e-5)
-    n = n.view(b, FR, tokens, CH) + pe[:FR].view(1, FR, 1, CH)
+    n = n.view(b, fr, tokens, CH) + pe[:fr].view(1, fr, 1, CH)
     qkv = n @ w.float().t()                                  # [b, f, n, 960]
-    q, k, v = (t.reshape(b, FR, tokens, HEADS, D).permute(0, 2, 3, 1, 4) for t in qkv.split(CH, dim=-1))  # [b, n, h, f, d]
+    q, k, v = (t.reshape(b, fr, tokens, HEADS, D).permute(0, 2, 3, 1, 4) for t in qkv.split(CH, dim=-1))  # [b, n, h, f, d]
     o = F.softmax(q @ k.transpose(-1, -2) * D ** -0.5, dim=-1) @ v
-    return o.permute(0, 3, 1, 2, 4).reshape(b * FR * tokens, CH)
+    return o.permute(0, 3, 1, 2, 4).reshape(b * fr * tokens, CH)
 
 
 def two_launch(x, w, gamma, beta, pe, b, tokens):
@@ -71,7 +71,7 @@ def make_out(dt, seed=11):
     return wo, bo
 
 
-def fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, wfrag=None, wofrag=None, residual=True):
+def fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, wfrag=None, wofrag=None, residual=True, fr=FR):
     """ABI v12: attention + output projection + bias + residual (the block's own input) in one launch."""
     from controlanimate_amd.layers import frag_order_wout
     if wfrag is None:
@@ -79,7 +79,7 @@ def fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, wfrag=None, wofrag=None,
     if wofrag is None:
         wofrag = frag_order_wout(wo.float()).to(x.dtype)
     bp = (pe + beta[None, :]).contiguous()
-    return K.tattn_fused(x, wfrag, gamma.contiguous(), bp, b, FR, tokens, HEADS, 1e-5, D ** -0.5, w_out_frag=wofrag, bias_out=bo,
+    return K.tattn_fused(x, wfrag, gamma.contiguous(), bp, b, fr, tokens, HEADS, 1e-5, D ** -0.5, w_out_frag=wofrag, bias_out=bo,
                          residual=x if residual else None)
 
 
