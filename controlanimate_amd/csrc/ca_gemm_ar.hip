@@ -175,7 +175,7 @@ extern "C" int ca_tattn_fused_supported(const ca_tattn_args* a) {
 
 extern "C" int ca_tattn_fused(const ca_tattn_args* a, void* stream) {
   CA_REQUIRE(a != nullptr, "ca_tattn_fused: null args");
-  CA_REQUIRE(ca_tattn_fused_supported(a), "ca_tattn_fused: arguments outside what the fused temporal attention takes (C = 320, 8 heads, 16 frames, tokens %% 8 == 0, "
+  CA_REQUIRE(ca_tattn_fused_supported(a), "ca_tattn_fused: arguments outside what the fused temporal attention takes (C = 320, 8 heads, 16 frames -- or 8 / 32 with w_out_frag --, tokens %% (128 / frames) == 0, "
                                            ">= 16384 rows, fragment-ordered weights, 16-byte aligned operands, 32-bit byte offsets): ask ca_tattn_fused_supported() first");
   const int64_t rows = (int64_t)a->batch * a->frames * a->tokens;
   TattnParams p{};
