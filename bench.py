@@ -338,10 +338,10 @@ class KernelTimer:
         rows = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:top]
         return [dict(op=k[0], shape=k[1:], launches=v["n"], ms=round(v["ms"], 3), avg_us=round(1e3 * v["ms"] / v["n"], 1)) for k, v in rows]
 
-    def by_shape(self, top=25):
+    def by_shape(self, top=40):
         agg = {}
         for name, flops, s, e, shape in self.records:
-            d = agg.setdefault((name.split("_")[0],) + shape, dict(n=0, flops=0.0, ms=0.0))
+            d = agg.setdefault((name,) + shape, dict(n=0, flops=0.0, ms=0.0))
             d["n"] += 1
             d["flops"] += flops
             d["ms"] += s.elapsed_time(e)

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CA_HIP_LIB") or os.path.join(_HERE, "csrc", "libcontr
 
 CA_BF16, CA_F16 = 0, 1
 CA_ACT_NONE, CA_ACT_SILU = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class CAHipUnavailable(RuntimeError):
@@ -73,6 +73,7 @@ class XattnArgs(C.Structure):
         ("nk", C.c_int32), ("heads", C.c_int32), ("c", C.c_int32),
         ("ln_eps", C.c_float), ("dtype", C.c_int32),
         ("w_out_frag", C.c_void_p), ("bias_out", C.c_void_p), ("residual", C.c_void_p), ("ld_res", C.c_int64),  # ABI v12
+        ("kv_frag_ip", C.c_void_p), ("nk_ip", C.c_int32), ("ip_scale", C.c_float),                              # ABI v13
     ]
 
 

@@ -36,6 +36,10 @@ class AttnProcessor2_0(nn.Module):
     def ip_branch(self, attn, q, ctx, out, images, tokens, kv_rows, frames_per_kv, kv_mod, cache):
         return out
 
+    def ip_fragments(self, attn, ctx, cache):
+        """(packed K / V fragments of the image-prompt tokens, their count, scale) for the one-launch form, or None: no such tokens."""
+        return None
+
     def __call__(self, attn: "Attention", hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
                  attention_mask=None, temb=None, *, residual: Optional[torch.Tensor] = None, frames_per_kv: int = 1,
                  kv_mod: int = 0, temporal=None, cache: Optional[dict] = None, ln=None, row_sums: bool = False) -> torch.Tensor:
@@ -60,11 +64,15 @@ class AttnProcessor2_0(nn.Module):
             if o is not None:
                 out = attn.to_out[0].run(o, residual=res, row_sums=row_sums)
                 return K.carry_row_sums(out.reshape(B, N, C), out)
+        builtin = type(self).ip_branch is AttnProcessor2_0.ip_branch
+        with_ip = (not builtin and type(self).ip_fragments is not AttnProcessor2_0.ip_fragments and dispatch.attn_out_fused and dispatch.xattn_ip_fused
+                   and getattr(attn, "ofrag", None) is not None)
         if (ln is not None and encoder_hidden_states is not None and cache is not None and getattr(attn, "xfrag", None) is not None
-                and type(self).ip_branch is AttnProcessor2_0.ip_branch):
-            # LayerNorm + to_q + attention over the text tokens in one launch where the library takes the shape (processors that need q
-            # again -- the IP-Adapter's second attention -- keep the separate launches).  The K / V fragments are packed once per
-            # window beside the projected K / V (refresh_window_caches repacks them in place).
+                and (builtin or with_ip)):
+            # LayerNorm + to_q + attention over the text tokens in one launch where the library takes the shape.  The K / V fragments are
+            # packed once per window beside the projected K / V (refresh_window_caches repacks them in place).  A processor with a second
+            # attention over image-prompt tokens (the IP-Adapter's) rides along only in the form that ends with the output projection
+            # (ABI v13: its q never leaves the kernel); otherwise it keeps the separate launches.
             ctx = encoder_hidden_states
             nb, L, cd = ctx.shape
             nk = L - self.num_tokens
@@ -78,11 +86,15 @@ class AttnProcessor2_0(nn.Module):
                 ofrag = getattr(attn, "ofrag", None)
                 if ofrag is not None and dispatch.attn_out_fused:  # ... and to_out + bias + residual in the same launch (ABI v12)
                     to_out = attn.to_out[0]
-                    out = K.xattn_fused(x, attn.xfrag.t, ln[1].b.t, ent[0], B, N, frames_per_kv, kv_mod, nk, ln[1].eps, w_out_frag=ofrag.t,
-                                        bias_out=None if to_out.b is None else to_out.b.t, residual=res)
-                    if out is not None:
-                        return out.reshape(B, N, C)
-                o = K.xattn_fused(x, attn.xfrag.t, ln[1].b.t, ent[0], B, N, frames_per_kv, kv_mod, nk, ln[1].eps)
+                    ipf = self.ip_fragments(attn, ctx, cache) if with_ip else None
+                    if not with_ip or ipf is not None:
+                        out = K.xattn_fused(x, attn.xfrag.t, ln[1].b.t, ent[0], B, N, frames_per_kv, kv_mod, nk, ln[1].eps, w_out_frag=ofrag.t,
+                                            bias_out=None if to_out.b is None else to_out.b.t, residual=res,
+                                            kv_frag_ip=None if ipf is None else ipf[0], nk_ip=0 if ipf is None else ipf[1],
+                                            ip_scale=1.0 if ipf is None else ipf[2])
+                        if out is not None:
+                            return out.reshape(B, N, C)
+                o = K.xattn_fused(x, attn.xfrag.t, ln[1].b.t, ent[0], B, N, frames_per_kv, kv_mod, nk, ln[1].eps) if builtin else None
                 if o is not None:
                     out = attn.to_out[0].run(o, residual=res, row_sums=row_sums)
                     return K.carry_row_sums(out.reshape(B, N, C), out)
@@ -134,7 +146,7 @@ class IPAttnProcessor2_0(AttnProcessor2_0):
     def pack(self, arena: WeightArena, dtype):
         self.kv_ip = pack_concat_rows(arena, dtype, [self.to_k_ip, self.to_v_ip])
 
-    def ip_branch(self, attn, q, ctx, out, images, tokens, kv_rows, frames_per_kv, kv_mod, cache):
+    def _kv_ip(self, ctx, cache):
         if self.kv_ip is None:
             raise RuntimeError("IPAttnProcessor2_0 installed after prepare(); call model.prepare() again")
         nb, L, cd = ctx.shape
@@ -143,6 +155,26 @@ class IPAttnProcessor2_0(AttnProcessor2_0):
             kvip = K.gemm(ctx.reshape(nb * L, cd), self.kv_ip.t)  # all rows; only the last num_tokens are read
             if cache is not None:
                 cache[("kv_ip", id(self))] = kvip
+        return kvip
+
+    def ip_fragments(self, attn, ctx, cache):
+        """The to_k_ip | to_v_ip projection of the image-prompt tokens as the MFMA fragments K.xattn_fused reads (packed once per window;
+        refresh_window_caches repacks in place), or None for shapes the one-launch form does not take."""
+        nb, L, cd = ctx.shape
+        if cache is None or not (1 <= self.num_tokens <= 16):
+            return None
+        ent = cache.get(("kvf_ip", id(self)))
+        if ent is None:
+            kvip = self._kv_ip(ctx, cache)
+            ent = cache[("kvf_ip", id(self))] = (K.xattn_pack_kv(kvip, nb, L, self.num_tokens, attn.scale, row_offset=L - self.num_tokens),
+                                                 self.num_tokens, L, attn.scale)
+        if ent[0] is None or ent[1] != self.num_tokens or ent[2] != L:
+            return None
+        return ent[0], self.num_tokens, float(self.scale)
+
+    def ip_branch(self, attn, q, ctx, out, images, tokens, kv_rows, frames_per_kv, kv_mod, cache):
+        nb, L, cd = ctx.shape
+        kvip = self._kv_ip(ctx, cache)
         return K.attention_cross(q, kvip, images, tokens, attn.heads, self.num_tokens, L, frames_per_kv, out=out,
                                  out_scale=float(self.scale), accumulate=True, kv_row_offset=L - self.num_tokens,
                                  kv_mod=kv_mod)

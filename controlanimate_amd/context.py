@@ -37,6 +37,7 @@ class Dispatch:
     tattn_fused = True    # ca_tattn_fused for the 64x64-latent motion modules
     xattn_fused = True    # ca_xattn_fused for the 64x64-latent text cross-attention
     attn_out_fused = True  # ... with the output projection + bias + residual as their last stage (ABI v12)
+    xattn_ip_fused = True  # ... the IP-Adapter's image-prompt attention inside the text cross-attention's launch (ABI v13)
     conv_winograd = True  # Winograd F(2x2, 3x3) form of the deep convolutions at the small-latent levels (read at prepare() time)
     gn_winograd = True    # ... with the GroupNorm in front writing the transformed input itself (ca_groupnorm_args.wino_v)
     ln_row_sums = True    # LayerNorm statistics from the producing GEMM's epilogue

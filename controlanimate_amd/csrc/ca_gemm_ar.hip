@@ -231,8 +231,8 @@ extern "C" int ca_xattn_pack_w(const void* w, int32_t n, int32_t k, void* dst, v
 extern "C" int ca_xattn_pack_kv(const void* kv, int64_t ld, int32_t kv_batches, int32_t rows_per_batch, int32_t row_offset, int32_t nk, float scale, int32_t dtype,
                                 void* dst, void* stream) {
   CA_REQUIRE(kv && dst, "ca_xattn_pack_kv: null operand");
-  CA_REQUIRE(kv_batches > 0 && rows_per_batch > 0 && row_offset >= 0 && nk > 64 && nk <= 80 && row_offset + nk <= rows_per_batch && ld >= 640,
-             "ca_xattn_pack_kv: kv_batches=%d rows_per_batch=%d row_offset=%d nk=%d (65..80) ld=%lld (>= 640: K | V of 8 heads x 40)", kv_batches, rows_per_batch, row_offset, nk,
+  CA_REQUIRE(kv_batches > 0 && rows_per_batch > 0 && row_offset >= 0 && ((nk > 64 && nk <= 80) || (nk >= 1 && nk <= 16)) && row_offset + nk <= rows_per_batch && ld >= 640,
+             "ca_xattn_pack_kv: kv_batches=%d rows_per_batch=%d row_offset=%d nk=%d (65..80 text keys, or 1..16 image-prompt tokens) ld=%lld (>= 640: K | V of 8 heads x 40)", kv_batches, rows_per_batch, row_offset, nk,
              (long long)ld);
   CA_REQUIRE(dtype == CA_BF16 || dtype == CA_F16, "ca_xattn_pack_kv: dtype %d", dtype);
   CA_REQUIRE(((uintptr_t)dst & 15) == 0 && scale > 0.f, "ca_xattn_pack_kv: dst must be 16-byte aligned, scale > 0");
@@ -260,6 +260,11 @@ extern "C" int ca_xattn_fused_supported(const ca_xattn_args* a) {
   if (((int64_t)(a->m - 1) * a->lda + 320) * 2 >= lim || ((int64_t)(a->m - 1) * a->ldo + 320) * 2 >= lim) return 0;
   if (!(a->ln_eps > 0.f)) return 0;
   if (!attn_out_args_ok(a->w_out_frag, a->bias_out, a->residual, a->ld_res, a->m)) return 0;
+  if (a->kv_frag_ip) {  // ABI v13: the image-prompt tokens ride on the eight-wave kernel (with the output stage) only
+    if (!a->w_out_frag || a->nk_ip < 1 || a->nk_ip > 16 || ((uintptr_t)a->kv_frag_ip & 15) != 0 || !(a->ip_scale == a->ip_scale) || a->ip_scale - a->ip_scale != 0.f) return 0;
+  } else if (a->nk_ip != 0) {
+    return 0;
+  }
   return 1;
 }
 
@@ -287,8 +292,12 @@ extern "C" int ca_xattn_fused(const ca_xattn_args* a, void* stream) {
     p.out.ld_res = (int)a->ld_res;
     p.out.res_bytes = a->residual ? (unsigned)(((int64_t)(a->m - 1) * a->ld_res + 320) * 2) : 0u;
     const unsigned grid1 = (unsigned)(tiles < ar_cu_count() ? tiles : ar_cu_count());
-    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_xattn_out<CA_BF16>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
-    else hipLaunchKernelGGL((k_xattn_out<CA_F16>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+    if (a->kv_frag_ip) {
+      p.kvf_ip = (const u16*)a->kv_frag_ip, p.nk_ip = a->nk_ip, p.ip_scale = a->ip_scale;
+      if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_xattn_out<CA_BF16, true>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+      else hipLaunchKernelGGL((k_xattn_out<CA_F16, true>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+    } else if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_xattn_out<CA_BF16, false>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
+    else hipLaunchKernelGGL((k_xattn_out<CA_F16, false>), dim3(grid1), dim3(512), 0, (hipStream_t)stream, p, tiles);
     CA_CHECK_LAUNCH("ca_xattn_fused(out)");
     return CA_OK;
   }

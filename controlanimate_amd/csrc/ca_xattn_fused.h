@@ -28,6 +28,11 @@ struct XattnParams {
   float ln_eps;
   unsigned x_bytes, o_bytes, kvf_bytes;
   AttnOutParams out;  // ABI v12: the output projection + bias + residual as the kernel's last stage (k_xattn_out)
+  // ABI v13: the IP-Adapter's image-prompt tokens (k_xattn_out<DT, true>): a second K / V set in the same fragment format (its first key tile
+  // only: nk_ip <= 16), its own softmax, o = o_text + ip_scale * o_ip before the output projection (modules/attention_processor.py:433-477)
+  const u16* kvf_ip;
+  int nk_ip;
+  float ip_scale;
 };
 
 constexpr int CA_XATTN_WF_ELEMS = 4 * 2 * 10 * 3 * 64 * 8;  // 122880
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void k_xattn_fused(XattnParams p, int tiles
 //   y = softmax(q K^T / sqrt(d)) V Wout^T + b_out + x        (animatediff/models/attention.py:253-262: `attn2(norm2(x), ehs) + x`)
 // The structure of k_tattn_out (ca_tattn_fused.h): one block of eight waves per CU, wave w = head w, the tile in one of two 80 KB
 // buffers (the next tile's DMA issued by waves 0..3 at the start of the K loops), o through LDS into the 64 x 80-per-wave output stage.
-template <int DT>
+template <int DT, bool IP>
 __global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) {
   constexpr int K = 320, KQ = 10, TM = 8, TJ = 3, BM = 128, HD = 40, KT = 5;
   constexpr int ROWB = K * 2, TILEB = BM * ROWB;
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) 
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.o, 0, p.o_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc((void*)p.kvf, 0, p.kvf_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_bi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.wf), 0, p.bias ? 320u * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_kvi = __builtin_amdgcn_make_buffer_rsrc((void*)(IP ? (const void*)p.kvf_ip : (const void*)p.kvf), 0, IP ? p.kvf_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc((void*)p.out.wof, 0, (unsigned)CA_WOUT_ELEMS * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_bo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out.bias ? (const void*)p.out.bias : (const void*)p.wf), 0, p.out.bias ? 320u * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out.res ? (const void*)p.out.res : (const void*)p.wf), 0, p.out.res ? p.out.res_bytes : 0u, 0x00020000);
@@ -383,6 +389,7 @@ __global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) 
     __builtin_amdgcn_sched_barrier(0);
 
     u32x2 kf[KT][TJ], vf[TJ][KT];
+    u32x2 kfi[TJ], vfi[TJ];
     u32x2 op[TM][TJ];
     {
       f32x4 acc[TM][TJ];
@@ -426,6 +433,12 @@ __global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) 
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) vf[j][kt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_kv, kvb, (unsigned)((15 + j * 5 + kt) * 512), 0));
+        if (IP) {  // key tile 0 of the image-prompt set: K fragments (0, c), V^T fragments (j, 0)
+#pragma unroll
+          for (int c = 0; c < TJ; ++c) kfi[c] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_kvi, kvb, (unsigned)(c * 512), 0));
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) vfi[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_kvi, kvb, (unsigned)((15 + j * 5) * 512), 0));
+        }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) bi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bi, (unsigned)(head * HD + 16 * j + 4 * gq) * 4u, 0, 0));
 #pragma unroll
@@ -435,6 +448,10 @@ __global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) 
             qp[i][j] = (u32x2){pack2<DT>(acc[i][j][0] + bi[j][0], acc[i][j][1] + bi[j][1]), pack2<DT>(acc[i][j][2] + bi[j][2], acc[i][j][3] + bi[j][3])};
       }
       __builtin_amdgcn_sched_barrier(0);
+      // IP: o goes into the tile as each row tile finishes (its 48 registers are what the second K / V set needs), so every wave must be
+      // through with its q pass on the normalised tile here already -- the barrier the plain variant has behind the attention
+      const int l15q = lane_q & 15;
+      if (IP) __syncthreads();
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         f32x4 st[KT];
@@ -466,12 +483,41 @@ __global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) 
           pp[kt] = (u32x2){pack2_prob<DT>(e[0], e[1]), pack2_prob<DT>(e[2], e[3])};
         }
         const float inv = __builtin_amdgcn_rcpf(rowgroup_sum(l));
+        u32x2 ppi;
+        float invi = 0.f;
+        if (IP) {  // the image-prompt tokens: their own softmax over <= 16 keys (only the lanes of key group 0..3 hold real scores)
+          f32x4 si = Elem<DT>::mfma16(kfi[0], qp[i][0], (f32x4){0.f, 0.f, 0.f, 0.f});
+          si = Elem<DT>::mfma16(kfi[1], qp[i][1], si);
+          si = Elem<DT>::mfma16(kfi[2], qp[i][2], si);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * gq + r >= p.nk_ip) si[r] = -INFINITY;
+          const float mi = rowgroup_max(fmaxf(fmaxf(si[0], si[1]), fmaxf(si[2], si[3])));
+          float ei[4], li = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ei[r] = __builtin_amdgcn_exp2f(si[r] - mi);
+            li += ei[r];
+          }
+          ppi = (u32x2){pack2_prob<DT>(ei[0], ei[1]), pack2_prob<DT>(ei[2], ei[3])};
+          invi = p.ip_scale * __builtin_amdgcn_rcpf(rowgroup_sum(li));
+        }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           f32x4 ot = Elem<DT>::mfma16(vf[j][0], pp[0], (f32x4){0.f, 0.f, 0.f, 0.f});  // O^T[d_v = 16 j + 4 g + r][row = l15]
 #pragma unroll
           for (int kt = 1; kt < KT; ++kt) ot = Elem<DT>::mfma16(vf[j][kt], pp[kt], ot);
-          op[i][j] = (u32x2){pack2<DT>(ot[0] * inv, ot[1] * inv), pack2<DT>(ot[2] * inv, ot[3] * inv)};
+          if (IP) {
+            const f32x4 oi = Elem<DT>::mfma16(vfi[j], ppi, (f32x4){0.f, 0.f, 0.f, 0.f});
+            const u32x2 ov = {pack2<DT>(fmaf(oi[0], invi, ot[0] * inv), fmaf(oi[1], invi, ot[1] * inv)), pack2<DT>(fmaf(oi[2], invi, ot[2] * inv), fmaf(oi[3], invi, ot[3] * inv))};
+            const int dv = 16 * j + 4 * gq;
+            if (dv < HD) {
+              const int col = head * HD + dv;
+              ca_lds_store8(xb + (16 * i + l15q) * ROWB + (((col >> 3) ^ ((l15q >> 1) & 7)) << 4) + (col & 7) * 2, ov);
+            }
+          } else {
+            op[i][j] = (u32x2){pack2<DT>(ot[0] * inv, ot[1] * inv), pack2<DT>(ot[2] * inv, ot[3] * inv)};
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -482,17 +528,19 @@ __global__ __launch_bounds__(512, 2) void k_xattn_out(XattnParams p, int tiles) 
     const unsigned row_base = (unsigned)(m0 + (wid >> 2) * 64 + l15e);
     AttnOutRegs R;
     attn_out_prefetch<DT>(R, p.out, rs_wo, rs_res, wid, lane_e, row_base, 16u, 32u);
-    __syncthreads();  // every wave has finished its K loop on the normalised tile
+    if (!IP) {
+      __syncthreads();  // every wave has finished its K loop on the normalised tile
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const int dv = 16 * j + 4 * ge;
-        if (dv < HD) {
-          const int col = head * HD + dv;
-          ca_lds_store8(xb + (16 * i + l15e) * ROWB + (((col >> 3) ^ ((l15e >> 1) & 7)) << 4) + (col & 7) * 2, op[i][j]);
+        for (int j = 0; j < TJ; ++j) {
+          const int dv = 16 * j + 4 * ge;
+          if (dv < HD) {
+            const int col = head * HD + dv;
+            ca_lds_store8(xb + (16 * i + l15e) * ROWB + (((col >> 3) ^ ((l15e >> 1) & 7)) << 4) + (col & 7) * 2, op[i][j]);
+          }
         }
-      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // the o tile is complete
     attn_out_run<DT>(R, xb, fa_b, p.out, rs_wo, rs_bo, rs_o, wid, lane_e, row_base, 16u, 32u, (unsigned)p.ldo);

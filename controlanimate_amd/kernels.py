@@ -213,8 +213,10 @@ def tattn_fused(x: torch.Tensor, w_frag: torch.Tensor, gamma: torch.Tensor, bias
 def xattn_pack_kv(kv: torch.Tensor, kv_batches: int, rows_per_batch: int, nk: int, scale: float, row_offset: int = 0,
                   out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """The K | V rows of `kv` [kv_batches * rows_per_batch, 2 * 320] as the MFMA fragments ca_xattn_fused reads (ca_xattn_pack_kv,
-    ABI v11; once per window and layer) -- or None for shapes the fused kernel does not take."""
-    if not dispatch.xattn_fused or kv.dim() != 2 or kv.shape[1] != 640 or kv.stride(1) != 1 or not (64 < nk <= 80) or kv.dtype not in (torch.float16, torch.bfloat16):
+    ABI v11; once per window and layer) -- or None for shapes the fused kernel does not take: 65..80 text keys, or (ABI v13) the 1..16
+    image-prompt tokens of the IP-Adapter's second attention (row_offset = the first of them)."""
+    if (not dispatch.xattn_fused or kv.dim() != 2 or kv.shape[1] != 640 or kv.stride(1) != 1 or not (64 < nk <= 80 or 1 <= nk <= 16)
+            or kv.dtype not in (torch.float16, torch.bfloat16)):
         return None
     _req_cuda(kv)
     dst = out if out is not None else torch.empty((kv_batches, 8, _capi.XATTN_KV_FRAG_ELEMS), device=kv.device, dtype=kv.dtype)
@@ -226,16 +228,20 @@ def xattn_pack_kv(kv: torch.Tensor, kv_batches: int, rows_per_batch: int, nk: in
 
 def xattn_fused(x: torch.Tensor, wq_frag: torch.Tensor, bias: Optional[torch.Tensor], kv_frag: torch.Tensor, images: int, tokens: int,
                 frames_per_kv: int, kv_mod: int, nk: int, ln_eps: float, *, w_out_frag: Optional[torch.Tensor] = None,
-                bias_out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                bias_out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, kv_frag_ip: Optional[torch.Tensor] = None,
+                nk_ip: int = 0, ip_scale: float = 1.0) -> Optional[torch.Tensor]:
     """o = softmax(q K^T scale) V with q = LayerNorm(x) Wq^T + bias in one launch (ca_xattn_fused, ABI v11: the text cross-attention of
     the 64x64-latent level) -- or None where the library does not take the arguments (the caller then runs the folded q GEMM and
     attention_cross).  kv_frag from xattn_pack_kv; image z uses its text batch (z // frames_per_kv) % kv_mod, kv_mod = 0 meaning `images`
     exactly as attention_cross does (the library refuses a launch that would index past the packed text batches).
     With w_out_frag (layers.frag_order_wout of to_out[0].weight; ABI v12) the launch also applies the output projection and returns
-    y = o Wout^T + bias_out + residual."""
+    y = o Wout^T + bias_out + residual.  With kv_frag_ip (xattn_pack_kv of the IP-Adapter's to_k_ip | to_v_ip projection of the nk_ip
+    image-prompt tokens; ABI v13, needs w_out_frag) o = o_text + ip_scale * softmax(q K_ip^T scale) V_ip before that projection."""
     if not dispatch.xattn_fused or kv_frag is None:
         return None
-    _req_cuda(x, wq_frag, bias, kv_frag, w_out_frag, bias_out, residual)
+    _req_cuda(x, wq_frag, bias, kv_frag, w_out_frag, bias_out, residual, kv_frag_ip)
+    if kv_frag_ip is not None and (w_out_frag is None or kv_frag_ip.shape != kv_frag.shape or kv_frag_ip.dtype != x.dtype or not kv_frag_ip.is_contiguous()):
+        return None
     if x.dim() != 2 or x.stride(1) != 1 or x.shape[0] != images * tokens:
         return None
     if w_out_frag is None and (bias_out is not None or residual is not None):
@@ -248,11 +254,12 @@ def xattn_fused(x: torch.Tensor, wq_frag: torch.Tensor, bias: Optional[torch.Ten
     args = XattnArgs(x=_p(x), wq_frag=_p(wq_frag), bias=_p(bias), kv_frag=_p(kv_frag), o=_p(o), lda=x.stride(0), ldo=o.stride(0), m=x.shape[0],
                      tokens=tokens, frames_per_kv=frames_per_kv, kv_mod=kv_mod if kv_mod > 0 else images, kv_batches=kv_frag.shape[0],
                      nk=nk, heads=8, c=c, ln_eps=float(ln_eps), dtype=dt_code(x.dtype), w_out_frag=_p(w_out_frag), bias_out=_p(bias_out),
-                     residual=_p(residual), ld_res=residual.stride(0) if residual is not None else 0)
+                     residual=_p(residual), ld_res=residual.stride(0) if residual is not None else 0, kv_frag_ip=_p(kv_frag_ip),
+                     nk_ip=nk_ip if kv_frag_ip is not None else 0, ip_scale=float(ip_scale) if kv_frag_ip is not None else 0.0)
     if not lib().ca_xattn_fused_supported(C.byref(args)):
         return None
     if _plan_sink is not None:
-        _plan_sink.append("xattn_out128" if w_out_frag is not None else "xattn_fused128")
+        _plan_sink.append(("xattn_ip_out128" if kv_frag_ip is not None else "xattn_out128") if w_out_frag is not None else "xattn_fused128")
     check(lib().ca_xattn_fused(C.byref(args), _stream()), "ca_xattn_fused")
     return o
 

@@ -138,6 +138,9 @@ class HipModelMixin:
             if kvip is not None:
                 K.gemm(ehs.reshape(nb * L, cd), proc.kv_ip.t, out=kvip)
                 n += 1
+                ent = cache.get(("kvf_ip", id(proc)))  # the image-prompt K / V as MFMA fragments (K.xattn_fused, ABI v13)
+                if ent is not None and ent[0] is not None:
+                    K.xattn_pack_kv(kvip, nb, ent[2], ent[1], ent[3], row_offset=ent[2] - ent[1], out=ent[0])
         return n
 
     def _pack_tree(self, m: nn.Module, arena: WeightArena):

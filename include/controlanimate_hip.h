@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 12
+#define CA_ABI_VERSION 13
 
 /* element types */
 #define CA_BF16 0
@@ -237,13 +237,21 @@ typedef struct ca_xattn_args {
   const float* bias_out;
   const void* residual;
   int64_t ld_res;
+  /* ABI v13: the IP-Adapter's image-prompt tokens in the same launch (modules/attention_processor.py:433-477, IPAttnProcessor2_0:
+   * `hidden = attention(q, K, V) + scale * attention(q, K_ip, V_ip)` before to_out).  kv_frag_ip: a second ca_xattn_pack_kv buffer
+   * (same kv_batches; packed from the to_k_ip | to_v_ip projection of the last nk_ip context rows, nk_ip 1..16); needs w_out_frag.
+   * NULL / 0 = no image-prompt tokens (as ABI v12). */
+  const void* kv_frag_ip;
+  int32_t nk_ip;
+  float ip_scale;
 } ca_xattn_args;
 int ca_xattn_fused(const ca_xattn_args* args, void* stream);
 int ca_xattn_fused_supported(const ca_xattn_args* args);
 /* dst[CA_XATTN_W_FRAG_ELEMS] = w[320, 320] in the per-head fragment order ca_xattn_args.wq_frag takes (head dim 40 padded to 48 with zero rows). */
 int ca_xattn_pack_w(const void* w, int32_t n, int32_t k, void* dst, void* stream);
 /* dst[kv_batches * 8 * CA_XATTN_KV_FRAG_ELEMS] = the K (columns 0..319, * scale * log2 e) and V (columns 320..639) rows
- * row_offset .. row_offset + nk of every batch of kv [kv_batches * rows_per_batch, ld] as MFMA fragments in lane order. */
+ * row_offset .. row_offset + nk of every batch of kv [kv_batches * rows_per_batch, ld] as MFMA fragments in lane order; nk 65..80 (the text keys) or, ABI v13,
+ * 1..16 (the image-prompt set: ca_xattn_args.kv_frag_ip). */
 int ca_xattn_pack_kv(const void* kv, int64_t ld, int32_t kv_batches, int32_t rows_per_batch, int32_t row_offset, int32_t nk, float scale, int32_t dtype,
                      void* dst, void* stream);
 /* bytes of split-K scratch this launch can use (0: it would not split) */

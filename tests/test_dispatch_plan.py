@@ -267,6 +267,14 @@ def test_fused_text_cross_attention_only_takes_what_it_implements(capi):
         assert lib.ca_xattn_pack_w(args[0], args[1], args[2], args[3], None) < 0
     assert lib.ca_xattn_pack_kv(FAKE, 640, 2, 77, 0, 64, 0.158, capi.CA_F16, FAKE, None) < 0   # 64 keys: not this kernel's
     assert lib.ca_xattn_pack_kv(FAKE, 640, 2, 77, 4, 77, 0.158, capi.CA_F16, FAKE, None) < 0   # rows beyond the batch
+    # ABI v13: the IP-Adapter's image-prompt tokens (1..16 of them) ride on the form with the output stage only
+    assert ok(kv_frag_ip=FAKE, nk_ip=4, ip_scale=1.0) == 0
+    out = dict(w_out_frag=FAKE, bias_out=FAKE, residual=FAKE, ld_res=320)
+    assert ok(**out) == 1 and ok(kv_frag_ip=FAKE, nk_ip=4, ip_scale=1.0, **out) == 1 and ok(kv_frag_ip=FAKE, nk_ip=16, ip_scale=0.0, **out) == 1
+    assert ok(kv_frag_ip=FAKE, nk_ip=0, ip_scale=1.0, **out) == 0 and ok(kv_frag_ip=FAKE, nk_ip=17, ip_scale=1.0, **out) == 0
+    assert ok(kv_frag_ip=FAKE + 8, nk_ip=4, ip_scale=1.0, **out) == 0 and ok(kv_frag_ip=FAKE, nk_ip=4, ip_scale=float("nan"), **out) == 0
+    assert ok(nk_ip=4, **out) == 0                                                              # a count without the fragments
+    assert lib.ca_xattn_pack_kv(FAKE, 640, 2, 81, 77, 17, 0.158, capi.CA_F16, FAKE, None) < 0  # 17 image-prompt tokens: not taken
 
 
 def attn_label(capi, *, images, nq, nk, heads, d, kind="self", accumulate=0, causal=0, mask=False):

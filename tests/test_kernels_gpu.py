@@ -872,6 +872,46 @@ def test_xattn_fused_with_output_projection_c320(dt, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.2e-2)])
+def test_xattn_fused_with_image_prompt_tokens_c320(dt, tol):
+    """ca_xattn_fused with kv_frag_ip (ABI v13): the IP-Adapter's cross-attention site -- attention over the text tokens, a second attention
+    of the same q over the image-prompt tokens (the last num_tokens context rows through to_k_ip / to_v_ip), `o + scale * o_ip`, to_out +
+    bias + residual -- in one launch, against fp32 torch (modules/attention_processor.py:433-477) and the four launches it replaces."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import xattn_check as X
+    from controlanimate_amd import kernels as K
+    for (images, tokens, L, nk, nip, fpk, kvb, lda, res, sc) in [(8, 2048, 81, 77, 4, 4, 2, 320, True, 1.0), (6, 3072, 88, 72, 16, 2, 3, 640, True, 0.6),
+                                                                 (16, 1024, 78, 77, 1, 8, 2, 320, False, 0.5)]:
+        x, wq, gamma, beta, kv = X.make(images, tokens, L, kvb, dt, lda=lda)
+        kvip = X.make(images, tokens, L, kvb, dt, seed=23, lda=lda)[4]
+        wo, bo = X.make_out(dt)
+        ref = (X.reference_ip(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, dt, sc) @ wo.float().t() + bo[None, :]
+               + (x.float() if res else 0.0))
+        K._plan_sink = labels = []
+        try:
+            y = X.fused_ip_out(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, wo, bo, sc, residual=res)
+        finally:
+            K._plan_sink = None
+        assert y is not None and labels == ["xattn_ip_out128"], "the library must take this shape"
+        assert torch.equal(y, X.fused_ip_out(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, wo, bo, sc, residual=res))
+        rel = ((y.float() - ref).norm() / ref.norm()).item()
+        old = X.separate_ip_out(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, wo, bo, sc, residual=res)
+        rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+        assert torch.isfinite(y.float()).all() and rel < tol and rel < 1.5 * rel_old + 1e-4, (rel, rel_old)
+        # the image-prompt tokens matter: without them the result is a different one
+        y0 = X.fused_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, bo, residual=res)
+        assert ((y0.float() - ref).norm() / ref.norm()).item() > 5 * rel
+    # the image-prompt set needs the output stage; more than 16 tokens are not taken
+    x, wq, gamma, beta, kv = X.make(8, 2048, 81, 2, dt)
+    wf, cs, bias = X.operands(x, wq, gamma, beta, dt)
+    from controlanimate_amd.layers import frag_order_xattn
+    kvf, kvf_ip = K.xattn_pack_kv(kv, 2, 81, 77, 40 ** -0.5), K.xattn_pack_kv(kv, 2, 81, 4, 40 ** -0.5, row_offset=77)
+    assert K.xattn_fused(x, frag_order_xattn(wf.float()).to(dt), bias, kvf, 8, 2048, 4, 2, 77, 1e-5, kv_frag_ip=kvf_ip, nk_ip=4) is None
+    assert K.xattn_pack_kv(kv, 2, 81, 17, 40 ** -0.5, row_offset=64) is None
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_ff_fused_with_proj_out_c320(dtype):
     """ca_ff_fused with w_out_frag (ABI v12): the feed-forward, the transformer's proj_out, its bias and the transformer's residual in one

@@ -101,6 +101,29 @@ def test_config4_full_size_ip_adapter_two_guess_mode_controlnets():
         same(a, b, f"ControlNet residual {k} with other image tokens")
     eps_o = unet.forward_nhwc(x2, 2, f, 500, torch.cat([pos_other, pos_other]).contiguous(), down, mid)
     assert not torch.equal(eps, eps_o)
+    # the five IP-Adapter sites of the 64x96-latent level run as ONE launch each (ABI v13: text + image-prompt attention + to_out +
+    # residual); the separate launches they replace give the same eps to fp16 rounding
+    from controlanimate_amd.context import dispatch
+    K._plan_sink = labels = []
+    try:
+        same(eps, unet.forward_nhwc(x2, 2, f, 500, prompt_same, down, mid), "a third identical forward")
+    finally:
+        K._plan_sink = None
+    assert labels.count("xattn_ip_out128") == 5 and labels.count("xattn_out128") == 0, {k: labels.count(k) for k in set(labels) if "attn" in k}
+    dispatch.xattn_ip_fused = False
+    try:
+        eps_sep = unet.forward_nhwc(x2, 2, f, 500, prompt_same, down, mid)
+    finally:
+        dispatch.xattn_ip_fused = True
+    # (two fp16 evaluations of the whole network that round at different places: 2.2e-3 measured, the same distance the Winograd and the
+    #  direct convolutions put between two runs in tests/test_fullsize_gpu.py; each is held to the oracle at the sizes the oracle reaches)
+    assert rel(eps, eps_sep) < 5e-3, rel(eps, eps_sep)
+    # a prompt tensor rewritten IN PLACE (what the pipeline does between windows): the cached text AND image-prompt K / V fragments
+    # are re-projected and repacked at their addresses (refresh_window_caches)
+    p2 = prompt_same.clone()
+    same(eps, unet.forward_nhwc(x2, 2, f, 500, p2, down, mid), "the same prompt in another tensor")
+    p2.copy_(torch.cat([pos_other, pos_other]))
+    same(eps_o, unet.forward_nhwc(x2, 2, f, 500, p2, down, mid), "the prompt tensor rewritten in place")
 
 
 def test_config5_full_size_32_frames_768():

@@ -12,6 +12,7 @@ ENV = {
     "CA_TATTN_FUSED": "tattn_fused",
     "CA_XATTN_FUSED": "xattn_fused",
     "CA_ATTN_OUT_FUSED": "attn_out_fused",
+    "CA_XATTN_IP_FUSED": "xattn_ip_fused",
     "CA_CONV_WINOGRAD": "conv_winograd",
     "CA_GN_WINOGRAD": "gn_winograd",
     "CA_LN_ROWSUMS": "ln_row_sums",

@@ -81,6 +81,70 @@ def two_launch_out(x, wq, gamma, beta, kv, images, tokens, L, nk, fpk, kvb, wo, 
     return K.gemm(o, wo, bias=bo, residual=x if residual else None)
 
 
+def reference_ip(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, dt, ip_scale):
+    """fp32: o_text + ip_scale * o_ip (modules/attention_processor.py:433-477; the image-prompt tokens are the last nip context rows)."""
+    wf = (wq * gamma[None, :]).to(dt).float()
+    n = F.layer_norm(x.float(), (CH,), None, None, 1e-5)
+    q = (n @ wf.t() + wq @ beta).view(images, tokens, HEADS, D).transpose(1, 2)
+    idx = (torch.arange(images, device=dev) // fpk) % kvb
+
+    def att(src, lo, hi):
+        k = src[:, :CH].float().view(kvb, L, HEADS, D)[:, lo:hi].transpose(1, 2)[idx]
+        v = src[:, CH:].float().view(kvb, L, HEADS, D)[:, lo:hi].transpose(1, 2)[idx]
+        return F.softmax(q @ k.transpose(-1, -2) * D ** -0.5, dim=-1) @ v
+    o = att(kv, 0, nk) + ip_scale * att(kvip, L - nip, L)
+    return o.transpose(1, 2).reshape(images * tokens, CH)
+
+
+def fused_ip_out(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, wo, bo, ip_scale, residual=True):
+    """ABI v13: text attention + the IP-Adapter's image-prompt attention + output projection + bias + residual in one launch."""
+    from controlanimate_amd.layers import frag_order_wout
+    wf, cs, bias = operands(x, wq, gamma, beta, x.dtype)
+    kvf = K.xattn_pack_kv(kv, kvb, L, nk, D ** -0.5)
+    kvf_ip = K.xattn_pack_kv(kvip, kvb, L, nip, D ** -0.5, row_offset=L - nip)
+    return K.xattn_fused(x, frag_order_xattn(wf.float()).to(x.dtype), bias, kvf, images, tokens, fpk, kvb, nk, 1e-5,
+                         w_out_frag=frag_order_wout(wo.float()).to(x.dtype), bias_out=bo, residual=x if residual else None,
+                         kv_frag_ip=kvf_ip, nk_ip=nip, ip_scale=ip_scale)
+
+
+def separate_ip_out(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, wo, bo, ip_scale, residual=True):
+    """What the product ran before: folded q GEMM, attention over the text tokens, the accumulating attention over the image-prompt
+    tokens (IPAttnProcessor2_0.ip_branch), to_out."""
+    wf, cs, bias = operands(x, wq, gamma, beta, x.dtype)
+    xc = x.contiguous()
+    q = K.gemm(xc, wf, bias=bias, ln=(K.RowStats(xc, 1e-5), cs))
+    o = K.attention_cross(q, kv, images, tokens, HEADS, nk, L, fpk, kv_mod=kvb)
+    o = K.attention_cross(q, kvip, images, tokens, HEADS, nip, L, fpk, out=o, out_scale=float(ip_scale), accumulate=True, kv_row_offset=L - nip, kv_mod=kvb)
+    return K.gemm(o, wo, bias=bo, residual=xc if residual else None)
+
+
+def check_ip():
+    bad = 0
+    for dt in (torch.float16, torch.bfloat16):
+        for (images, tokens, L, nk, nip, fpk, kvb, lda, res, sc) in [(32, 4096, 81, 77, 4, 16, 2, 320, True, 1.0), (8, 2048, 81, 77, 4, 4, 2, 320, True, 0.6),
+                                                                     (6, 3072, 88, 72, 16, 2, 3, 640, True, 1.0), (16, 1024, 78, 77, 1, 8, 2, 320, False, 0.5)]:
+            x, wq, gamma, beta, kv = make(images, tokens, L, kvb, dt, lda=lda)
+            kvip = make(images, tokens, L, kvb, dt, seed=23, lda=lda)[4]
+            wo, bo = make_out(dt)
+            ref = (reference_ip(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, dt, sc) @ wo.float().t() + bo[None, :]
+                   + (x.float() if res else 0.0))
+            outs = [fused_ip_out(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, wo, bo, sc, residual=res) for _ in range(3)]
+            if outs[0] is None:
+                print(f"ip  {str(dt)[6:]:9s} images={images} tokens={tokens}: not taken by the library   <<<<<< FAIL")
+                bad += 1
+                continue
+            old = separate_ip_out(x, wq, gamma, beta, kv, kvip, images, tokens, L, nk, nip, fpk, kvb, wo, bo, sc, residual=res)
+            rel = ((outs[0].float() - ref).norm() / ref.norm()).item()
+            rel_old = ((old.float() - ref).norm() / ref.norm()).item()
+            det = all(torch.equal(outs[0], o) for o in outs[1:])
+            tol = 2e-3 if dt == torch.float16 else 1.2e-2
+            ok = rel < tol and rel < 1.5 * rel_old + 1e-4 and det and bool(torch.isfinite(outs[0].float()).all())
+            bad += not ok
+            print(f"ip  {str(dt)[6:]:9s} images={images} tokens={tokens:5d} L={L} nk={nk} nip={nip} scale={sc} lda={lda} residual={res}: rel {rel:.2e} "
+                  f"(separate launches {rel_old:.2e}) deterministic={det}{'' if ok else '   <<<<<< FAIL'}", flush=True)
+    return bad
+
+
 def check_out():
     bad = 0
     for dt in (torch.float16, torch.bfloat16):
@@ -176,11 +240,28 @@ def timing():
                 row.append(("fused+out", timeit(lambda: K.xattn_fused(x, packed[0], bias, packed[1], images, tokens, fpk, kvb, nk, 1e-5, w_out_frag=wol, bias_out=bo, residual=x))))
                 row.append(("fused, to_out", timeit(lambda: K.gemm(K.xattn_fused(x, packed[0], bias, packed[1], images, tokens, fpk, kvb, nk, 1e-5), wo, bias=bo, residual=x))))
             print(f"time {str(dt)[6:]:9s} rows {images * tokens:7d}: " + "  ".join(f"{n} {us:7.1f} us" for n, us in row), flush=True)
+            if tokens == 4096:  # the IP-Adapter's site (config 4): 77 text + 4 image-prompt tokens
+                L2_, nip = 81, 4
+                kv2 = make(images, tokens, L2_, kvb, dt)[4]
+                kvip = make(images, tokens, L2_, kvb, dt, seed=23)[4]
+                kvf, kvf_ip = K.xattn_pack_kv(kv2, kvb, L2_, 77, D ** -0.5), K.xattn_pack_kv(kvip, kvb, L2_, nip, D ** -0.5, row_offset=L2_ - nip)
+
+                def sep():
+                    q = K.gemm(x, wf, bias=bias, ln=(K.RowStats(x, 1e-5), cs))
+                    o = K.attention_cross(q, kv2, images, tokens, HEADS, 77, L2_, fpk, kv_mod=kvb)
+                    o = K.attention_cross(q, kvip, images, tokens, HEADS, nip, L2_, fpk, out=o, out_scale=1.0, accumulate=True, kv_row_offset=L2_ - nip, kv_mod=kvb)
+                    return K.gemm(o, wo, bias=bo, residual=x)
+                row = []
+                for _ in range(2):
+                    row.append(("fused+ip+out", timeit(lambda: K.xattn_fused(x, packed[0], bias, kvf, images, tokens, fpk, kvb, 77, 1e-5, w_out_frag=wol, bias_out=bo,
+                                                                             residual=x, kv_frag_ip=kvf_ip, nk_ip=nip, ip_scale=1.0))))
+                    row.append(("gemm, attn, attn ip, to_out", timeit(sep)))
+                print(f"time {str(dt)[6:]:9s} rows {images * tokens:7d} (IP tokens): " + "  ".join(f"{n} {us:7.1f} us" for n, us in row), flush=True)
 
 
 if __name__ == "__main__":
     rc = 0
     if "--time-only" not in sys.argv:
-        rc = check() + check_out()
+        rc = check() + check_out() + check_ip()
     timing()
     sys.exit(1 if rc else 0)
