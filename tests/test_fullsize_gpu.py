@@ -39,11 +39,70 @@ def test_config1_full_width_unet_eps_vs_oracle():
     assert not missing and not unexpected
     del w
     m.to(DEV).prepare(DEV, torch.float16)
-    out = m(x.to(DEV), 500, ehs.to(DEV)).sample
+    from controlanimate_amd import kernels as K
+    K._plan_sink = labels = []
+    try:
+        out = m(x.to(DEV), 500, ehs.to(DEV)).sample
+    finally:
+        K._plan_sink = None
     torch.cuda.synchronize()
+    # 2 x 8 frames x 1024 tokens = 16384 rows: the one-launch forms of the C = 320 level run here too -- the temporal one in its
+    # 8-frame form (two pixels per MFMA row tile)
+    assert labels.count("tattn_out128") == 10 and labels.count("xattn_out128") == 5 and labels.count("ff_out128") >= 5, \
+        {k: labels.count(k) for k in set(labels) if "out128" in k}
     r = rel(out, ref)
     print(f"full-width config-1 UNet3D eps rel_l2 = {r:.3e}")
     assert r < 1e-2, f"rel_l2 {r:.3e}"   # BASELINE north_star tolerance
+
+
+def test_ip_adapter_sites_full_width_eps_vs_oracle():
+    """The IP-Adapter's UNet (modules/ip_adapter.py:95-127: IPAttnProcessor2_0 on the 16 attn2 sites; modules/attention_processor.py:433-477)
+    at full width against the fp32 oracle, at a size where the five 64x64-latent sites run in their one-launch form (ABI v13: text
+    attention + image-prompt attention + to_out + residual; 4 frames x 4096 tokens = 16384 rows)."""
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0
+    from controlanimate_amd.configs import unet_config
+    from controlanimate_amd.unet import UNet3DConditionModel
+    from oracle.unet3d import UNet3DConfig, init_unet3d_weights, unet3d_forward
+    cfg = UNet3DConfig.v2()
+    w = init_unet3d_weights(cfg, seed=0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 4, 4, 64, 64, generator=g)
+    ehs = torch.cat([torch.randn(1, 77, 768, generator=g) * 0.5, torch.randn(1, 4, 768, generator=g)], 1)
+    m = UNet3DConditionModel.from_config(unet_config("v2"))
+    missing, unexpected = m.load_state_dict(w, strict=False)
+    assert not missing and not unexpected
+    ip, procs = {}, {}
+    for name in m.attn_processors.keys():
+        if "attn2" not in name:
+            procs[name] = AttnProcessor2_0()
+            continue
+        hidden = m.get_submodule(name[: -len(".processor")]).to_q.out_features
+        p = IPAttnProcessor2_0(hidden_size=hidden, cross_attention_dim=768, scale=0.6, num_tokens=4)
+        k = torch.randn(hidden, 768, generator=g) * 768 ** -0.5
+        v = torch.randn(hidden, 768, generator=g) * 768 ** -0.5
+        p.to_k_ip.weight.data.copy_(k)
+        p.to_v_ip.weight.data.copy_(v)
+        procs[name] = p
+        ip[name[: -len(".processor")]] = {"to_k_ip": k, "to_v_ip": v, "scale": 0.6, "num_tokens": 4}
+    assert len(ip) == 16
+    with torch.no_grad():
+        ref = unet3d_forward(w, cfg, x, 500, ehs, ip=ip)
+        ref_text_only = unet3d_forward(w, cfg, x, 500, ehs[:, :77])
+    del w
+    m.set_attn_processor(procs)
+    m.to(DEV).prepare(DEV, torch.float16)
+    K._plan_sink = labels = []
+    try:
+        out = m(x.to(DEV), 500, ehs.to(DEV)).sample
+    finally:
+        K._plan_sink = None
+    torch.cuda.synchronize()
+    assert labels.count("xattn_ip_out128") == 5, {k: labels.count(k) for k in set(labels) if "attn" in k}
+    r = rel(out, ref)
+    print(f"full-width IP-Adapter UNet3D eps rel_l2 = {r:.3e} (the image-prompt tokens move eps by {rel(ref_text_only, ref):.3e})")
+    assert r < 1e-2, f"rel_l2 {r:.3e}"      # BASELINE north_star tolerance
+    assert rel(ref_text_only, ref) > 10 * r  # ... and the comparison would see the tokens missing
 
 
 def test_config2_full_size_eps_vs_oracle():
