@@ -55,6 +55,38 @@ def test_config1_full_width_unet_eps_vs_oracle():
     assert r < 1e-2, f"rel_l2 {r:.3e}"   # BASELINE north_star tolerance
 
 
+def test_32_frames_full_width_unet_eps_vs_oracle():
+    """BASELINE config 5's frame count (32 = the length of the v2 motion modules' positional table) at full width against the fp32
+    oracle: the temporal attention of the C = 320 level runs in its 32-frame one-launch form (two MFMA row tiles per pixel, 2 x 2 score
+    blocks; /root/reference/animatediff/models/motion_module.py:251-331)."""
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.configs import unet_config
+    from controlanimate_amd.unet import UNet3DConditionModel
+    from oracle.unet3d import UNet3DConfig, init_unet3d_weights, unet3d_forward
+    cfg = UNet3DConfig.v2()
+    w = init_unet3d_weights(cfg, seed=0)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 4, 32, 32, 32, generator=g)
+    ehs = torch.randn(1, 77, 768, generator=g) * 0.5
+    with torch.no_grad():
+        ref = unet3d_forward(w, cfg, x, 500, ehs)
+    m = UNet3DConditionModel.from_config(unet_config("v2"))
+    missing, unexpected = m.load_state_dict(w, strict=False)
+    assert not missing and not unexpected
+    del w
+    m.to(DEV).prepare(DEV, torch.float16)
+    K._plan_sink = labels = []
+    try:
+        out = m(x.to(DEV), 500, ehs.to(DEV)).sample
+    finally:
+        K._plan_sink = None
+    torch.cuda.synchronize()
+    assert labels.count("tattn_out128") == 10, {k: labels.count(k) for k in set(labels) if "attn" in k}
+    r = rel(out, ref)
+    print(f"full-width 32-frame UNet3D eps rel_l2 = {r:.3e}")
+    assert r < 1e-2, f"rel_l2 {r:.3e}"   # BASELINE north_star tolerance
+
+
 def test_ip_adapter_sites_full_width_eps_vs_oracle():
     """The IP-Adapter's UNet (modules/ip_adapter.py:95-127: IPAttnProcessor2_0 on the 16 attn2 sites; modules/attention_processor.py:433-477)
     at full width against the fp32 oracle, at a size where the five 64x64-latent sites run in their one-launch form (ABI v13: text
