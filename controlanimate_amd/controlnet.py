@@ -256,11 +256,18 @@ class MultiControlNetModel(nn.Module):
         return self
 
     def forward_bodies(self, x, timestep, encoder_hidden_states, controlnet_cond: Sequence[torch.Tensor],
-                       conditioning_scale: Sequence[float], guess_mode: bool = False, cfg_identical_halves: bool = False):
+                       conditioning_scale: Sequence[float], guess_mode: bool = False, cfg_identical_halves: bool = False, streams=None):
         """Every net up to its zero convolutions (see ControlNetModel.forward_body): the part of the stack that does not need
-        the UNet's skip tensors."""
-        return [net.forward_body(x, timestep, encoder_hidden_states, cond, scale, guess_mode, cfg_identical_halves)
-                for net, cond, scale in zip(self.nets, controlnet_cond, conditioning_scale)]
+        the UNet's skip tensors.  streams: HIP streams to spread the nets over, round-robin (net i on streams[i % len]) -- the bodies are
+        independent of each other; the caller orders the streams before (inputs) and after (the zero convolutions read every body)."""
+        bodies = []
+        for i, (net, cond, scale) in enumerate(zip(self.nets, controlnet_cond, conditioning_scale)):
+            if streams:
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    bodies.append(net.forward_body(x, timestep, encoder_hidden_states, cond, scale, guess_mode, cfg_identical_halves))
+            else:
+                bodies.append(net.forward_body(x, timestep, encoder_hidden_states, cond, scale, guess_mode, cfg_identical_halves))
+        return bodies
 
     def finish(self, bodies, base: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None):
         """Zero convolutions of every net, summed -- on top of `base` = (the UNet's skips, its mid-block output) when given."""

@@ -30,4 +30,7 @@ def apply_from_env() -> dict:
         if os.environ.get(var, "1") == "0":
             setattr(dispatch, attr, False)
             off[var] = attr
+    if os.environ.get("CA_CONTROLNET_STREAMS"):  # (an integer: streams a multi-ControlNet stack is spread over)
+        dispatch.controlnet_streams = int(os.environ["CA_CONTROLNET_STREAMS"])
+        off["CA_CONTROLNET_STREAMS"] = "controlnet_streams=%d" % dispatch.controlnet_streams
     return off
