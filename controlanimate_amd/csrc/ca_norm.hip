@@ -530,9 +530,11 @@ __global__ __launch_bounds__(256) void k_gn_small_wino(GnParams p) {
 // group, 1024 threads x up to 20 chunks in registers (64x64 latents: 4096 rows x 5 chunks exactly).  Read once, write
 // once: 168 MB instead of 252 MB at [32, 64, 64, 320].  The units of one image sit on one XCD (their 80-byte pieces
 // share 128-byte lines).  A chunk touches at most two groups: (first part, second part) sums as in k_gn_stats.
+// NCH = chunks a thread holds: 20 (64x64 latents: one block per CU) or 5 (32x32 latents and below, <= 5120 chunks per unit: the block's
+// registers then allow two blocks per CU, whose load, arithmetic and store phases overlap -- round 5).
 constexpr int GNU_MAX = 20;
-template <int DT>
-__global__ __launch_bounds__(1024) void k_gn_unit(GnParams p, int uc, int units) {
+template <int DT, int NCH>
+__global__ __launch_bounds__(1024, NCH <= 5 ? 2 : 1) void k_gn_unit(GnParams p, int uc, int units) {
   __shared__ float red[16][4][2];
   __shared__ float mr[4][2];
   __shared__ __attribute__((aligned(16))) float sc[128], sh[128];
@@ -552,9 +554,9 @@ __global__ __launch_bounds__(1024) void k_gn_unit(GnParams p, int uc, int units)
   const int total = (int)p.rows_per_stat * q;
   const int64_t base_row = (int64_t)sg * p.rows_per_stat;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  u32x4 raw[GNU_MAX];
+  u32x4 raw[NCH];
 #pragma unroll
-  for (int k = 0; k < GNU_MAX; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int id = threadIdx.x + k * 1024;
     if (id < total) {
       const int row = id / q, ch = unit * uc + (id - row * q) * 8;
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(1024) void k_gn_unit(GnParams p, int uc, int units)
   }
   float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-  for (int k = 0; k < GNU_MAX; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int id = threadIdx.x + k * 1024;
     if (id < total) {
       const int cq = id % q;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(1024) void k_gn_unit(GnParams p, int uc, int units)
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < GNU_MAX; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int id = threadIdx.x + k * 1024;
     if (id < total) {
       const int row = id / q, cq = id - row * q;
@@ -996,8 +998,15 @@ extern "C" int ca_groupnorm(const ca_groupnorm_args* a, void* stream) {
   if (const int uc = gn_unit_channels(p)) {
     const int units = (p.c1 + p.c2) / uc;
     const dim3 grid(units * (a->images / a->frames_per_stat));
-    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_gn_unit<CA_BF16>), grid, dim3(1024), 0, (hipStream_t)stream, p, uc, units);
-    else hipLaunchKernelGGL((k_gn_unit<CA_F16>), grid, dim3(1024), 0, (hipStream_t)stream, p, uc, units);
+    static const int gnu_small = CA_KNOB("CA_GN_UNIT_SMALL", 1);  // (experiments: 0 = the 20-chunk instantiation for every size)
+    const bool few = gnu_small && (int64_t)p.rows_per_stat * (uc >> 3) <= 1024 * 5;
+    if (a->dtype == CA_BF16) {
+      if (few) hipLaunchKernelGGL((k_gn_unit<CA_BF16, 5>), grid, dim3(1024), 0, (hipStream_t)stream, p, uc, units);
+      else hipLaunchKernelGGL((k_gn_unit<CA_BF16, GNU_MAX>), grid, dim3(1024), 0, (hipStream_t)stream, p, uc, units);
+    } else {
+      if (few) hipLaunchKernelGGL((k_gn_unit<CA_F16, 5>), grid, dim3(1024), 0, (hipStream_t)stream, p, uc, units);
+      else hipLaunchKernelGGL((k_gn_unit<CA_F16, GNU_MAX>), grid, dim3(1024), 0, (hipStream_t)stream, p, uc, units);
+    }
     CA_CHECK_LAUNCH("ca_groupnorm");
     return CA_OK;
   }
