@@ -737,7 +737,7 @@ def main():
     host_enqueue = time.perf_counter() - t0  # the calls have returned (a paced pipeline has also slept until its window was done)
     host_cpu = time.process_time() - c0      # CPU time of the process (all threads) over the same calls
     th1 = thread_cpu_seconds()
-    host_threads = sorted(((th1[k] - th0.get(k, 0.0), k) for k in th1), reverse=True)[:3]
+    host_threads = [t for t in sorted(((th1[k] - th0.get(k, 0.0), k) for k in th1), reverse=True) if t[0] > 0.0][:12]
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -814,7 +814,7 @@ def main():
         # an idle queue, ~12 ms behind a running step), so this is mostly waiting, not work
         "host_cpu_ms_per_step": round(1e3 * host_cpu / args.steps, 3),
         "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
-        "host_cpu_ms_per_step_by_thread": {k.split(":", 1)[1] + "#" + k.split(":", 1)[0]: round(1e3 * d / args.steps, 3) for d, k in host_threads},  # the three busiest
+        "host_cpu_ms_per_step_by_thread": {k.split(":", 1)[1] + "#" + k.split(":", 1)[0]: round(1e3 * d / args.steps, 3) for d, k in host_threads},  # every thread that used CPU (at most 12; /proc granularity 10 ms over the region)
         "steps_in_flight": int(pipe.steps_in_flight), "pace_wait": str(pipe.pace_wait),
         "step_algorithmic_tflop": round(step_tflop, 2),
         # utilisation of the dense MFMA peak by the work that was EXECUTED (the shared CFG prefix runs once: see below);
