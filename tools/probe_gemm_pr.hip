@@ -33,14 +33,21 @@ __global__ void k_fill(_Float16* p, size_t n, unsigned seed, float scale, int ze
   p[i] = zeros ? (_Float16)0.f : (_Float16)(s * 1.732f * scale);
 }
 
-template <int ABL>  // timing-only ablations (results wrong): 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no barriers, 8 = no MFMAs
-__global__ __launch_bounds__(256) void k_gemm_pr(const _Float16* __restrict__ A, const _Float16* __restrict__ W, _Float16* __restrict__ C, int M, int N, int K, int tiles_n) {
+template <int ABL, int UNIT>  // UNIT = 1: the two 32-deep halves of a 128-byte line are requested back to back (units of two steps)
+// timing-only ablations (results wrong): 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no barriers, 8 = no MFMAs
+__global__ __launch_bounds__(256) void k_gemm_pr(const _Float16* __restrict__ A, const _Float16* __restrict__ W, _Float16* __restrict__ C, int M, int N, int K, int tiles_n, int xmap) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
   const int g = lane >> 4, l15 = lane & 15;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  if (xmap) {  // XCD-compact: the 32 blocks an XCD runs at a time are a 4 x 8 patch of tiles (round-robin dispatch: XCD = blockIdx % 8)
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = (int)gridDim.x >> 3;  // tiles per XCD = 4 tile rows x tiles_n
+    const int grp = idx >> 5, r = idx & 31;
+    tm = xcd * (per / tiles_n) + (r & 3);
+    tn = grp * 8 + (r >> 2);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const unsigned a_bytes = (unsigned)((size_t)M * K * 2), w_bytes = (unsigned)((size_t)N * K * 2);
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
@@ -82,11 +89,33 @@ __global__ __launch_bounds__(256) void k_gemm_pr(const _Float16* __restrict__ A,
   f16x8 xa[2][8], wa[2][8];
 
   const int ns = K / KS;  // (even, >= 2: K % 64 == 0)
-  issue(0);
-  issue(1);
-  issue(2);
-  issue(3);
-  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // stage 0 landed (loads return in order)
+  auto issue_unit = [&](int u) __attribute__((always_inline)) {  // stages 2u, 2u + 1: piece by piece, the two halves of its lines back to back
+    unsigned char* b0 = smem + ((2 * u) & (NST - 1)) * STAGE_B;
+    unsigned char* b1 = smem + ((2 * u + 1) & (NST - 1)) * STAGE_B;
+    const unsigned k0 = (unsigned)(2 * u) * (KS * 2), k1 = k0 + KS * 2;
+    const bool live = 2 * u * KS < K;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(b0 + (wid * 4 + q) * 1024), 16, live ? va[q] : 0x80000000u, k0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(b1 + (wid * 4 + q) * 1024), 16, live ? va[q] : 0x80000000u, k1, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b0 + OFF_W + (wid * 4 + q) * 1024), 16, live ? vw[q] : 0x80000000u, k0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b1 + OFF_W + (wid * 4 + q) * 1024), 16, live ? vw[q] : 0x80000000u, k1, 0, 0);
+    }
+  };
+  if (UNIT) {
+    issue_unit(0);
+    issue_unit(1);
+  } else {
+    issue(0);
+    issue(1);
+    issue(2);
+    issue(3);
+  }
+  if (UNIT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // unit 0 landed
+  else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // stage 0 landed (loads return in order)
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -100,7 +129,7 @@ __global__ __launch_bounds__(256) void k_gemm_pr(const _Float16* __restrict__ A,
 #define PR_MFMA(ACC, WA, XA) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(WA), "v"(XA) : "memory")
   auto step = [&](int s, auto CUR) __attribute__((always_inline)) {
     constexpr int cur = decltype(CUR)::value;
-    if (ABL & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if ((ABL & 1) || (UNIT && cur == 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (UNIT, odd step: the next unit, whole)
     else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");  // stage s + 1 landed (s + 2, s + 3 may be outstanding); set CUR complete
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
     unsigned char* const nb = smem + ((s + 1) & (NST - 1)) * STAGE_B;
@@ -116,7 +145,16 @@ __global__ __launch_bounds__(256) void k_gemm_pr(const _Float16* __restrict__ A,
         if (r < 8) xa[cur ^ 1][r] = *reinterpret_cast<const f16x8*>(nb + fx + r * 1024);
         else wa[cur ^ 1][r - 8] = *reinterpret_cast<const f16x8*>(nb + fw + (r - 8) * 1024);
       }
-      if (!(ABL & 1) && idx >= 32 && (idx & 3) == 3) {
+      if (UNIT && !(ABL & 1) && cur == 1 && (idx & 3) == 3) {  // odd step: unit (s + 3) / 2 into the buffers of steps s - 1 and s, one request per four MFMAs
+        const int q = idx >> 2;  // 0 .. 15: A piece q >> 1 half q & 1 (0 .. 7), then W
+        const int pc = (q & 7) >> 1, hf = q & 1;
+        unsigned char* ub = smem + ((s + 3 + hf) & (NST - 1)) * STAGE_B;
+        const unsigned uk = (unsigned)(s + 3 + hf) * (KS * 2);
+        const bool ulive = (s + 3) * KS < K;
+        if (q < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(ub + (wid * 4 + pc) * 1024), 16, ulive ? va[pc] : 0x80000000u, uk, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(ub + OFF_W + (wid * 4 + pc) * 1024), 16, ulive ? vw[pc] : 0x80000000u, uk, 0, 0);
+      }
+      if (!UNIT && !(ABL & 1) && idx >= 32 && (idx & 3) == 3) {
         const int q = (idx - 32) >> 2;  // 0 .. 7: A pieces, then W pieces
         if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(db + (wid * 4 + q) * 1024), 16, live ? va[q] : 0x80000000u, koff, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(db + OFF_W + (wid * 4 + q - 4) * 1024), 16, live ? vw[q - 4] : 0x80000000u, koff, 0, 0);
@@ -152,24 +190,34 @@ __global__ void k_check(const _Float16* A, const _Float16* W, const _Float16* C,
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
-typedef void (*kern_t)(const _Float16*, const _Float16*, _Float16*, int, int, int, int);
-static kern_t pick(int abl) {
+typedef void (*kern_t)(const _Float16*, const _Float16*, _Float16*, int, int, int, int, int);
+static kern_t pick(int abl, int unit) {
+  if (unit) {
+    switch (abl) {
+      case 8: return k_gemm_pr<8, 1>;
+      case 10: return k_gemm_pr<10, 1>;
+      default: return k_gemm_pr<0, 1>;
+    }
+  }
   switch (abl) {
-    case 1: return k_gemm_pr<1>;
-    case 2: return k_gemm_pr<2>;
-    case 3: return k_gemm_pr<3>;
-    case 4: return k_gemm_pr<4>;
-    case 7: return k_gemm_pr<7>;
-    case 8: return k_gemm_pr<8>;
-    case 9: return k_gemm_pr<9>;
-    case 10: return k_gemm_pr<10>;
-    default: return k_gemm_pr<0>;
+    case 1: return k_gemm_pr<1, 0>;
+    case 2: return k_gemm_pr<2, 0>;
+    case 3: return k_gemm_pr<3, 0>;
+    case 4: return k_gemm_pr<4, 0>;
+    case 7: return k_gemm_pr<7, 0>;
+    case 8: return k_gemm_pr<8, 0>;
+    case 9: return k_gemm_pr<9, 0>;
+    case 10: return k_gemm_pr<10, 0>;
+    default: return k_gemm_pr<0, 0>;
   }
 }
 
 int main(int argc, char** argv) {
   const int abl = getenv("PR_ABL") ? atoi(getenv("PR_ABL")) : 0;
-  kern_t kern = pick(abl);
+  const int unit = getenv("PR_UNIT") ? atoi(getenv("PR_UNIT")) : 0;
+  kern_t kern = pick(abl, unit);
+  const int xmap_req = getenv("PR_MAP") ? atoi(getenv("PR_MAP")) : 0;
+  if (unit) printf("units of two steps (whole 128-byte lines requested back to back)\n");
   if (abl) printf("ablation %d (results wrong)\n", abl);
   std::vector<int> shapes = {8192, 10240, 1280, 32768, 5120, 640, 8192, 3840, 1280, 8192, 1280, 5120, 8192, 1280, 1280, 32768, 1920 + 128, 640};
   if (argc == 4) shapes = {atoi(argv[1]), atoi(argv[2]), atoi(argv[3])};
@@ -187,7 +235,8 @@ int main(int argc, char** argv) {
       k_fill<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(W, (size_t)N * K, 77u, 1.f / sqrtf((float)K), zeros);
       CK(hipMemset(C, 0xff, (size_t)M * N * 2));
       const int tiles_n = N / BN, tiles = (M / BM) * tiles_n;
-      hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 0, 0, A, W, C, M, N, K, tiles_n);
+      const int xmap = xmap_req && (M / BM) == 32 && tiles_n % 8 == 0;  // (the mapping above: 8 XCDs x 4 tile rows)
+      hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 0, 0, A, W, C, M, N, K, tiles_n, xmap);
       CK(hipDeviceSynchronize());
       CK(hipMemset(err, 0, 4));
       k_check<<<64, 256>>>(A, W, C, M, N, K, 64 * 256, err);
@@ -196,10 +245,10 @@ int main(int argc, char** argv) {
       hipEvent_t e0, e1;
       CK(hipEventCreate(&e0));
       CK(hipEventCreate(&e1));
-      for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 0, 0, A, W, C, M, N, K, tiles_n);
+      for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 0, 0, A, W, C, M, N, K, tiles_n, xmap);
       CK(hipEventRecord(e0));
       const int iters = 20;
-      for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 0, 0, A, W, C, M, N, K, tiles_n);
+      for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 0, 0, A, W, C, M, N, K, tiles_n, xmap);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms = 0.f;
