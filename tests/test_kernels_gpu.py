@@ -1047,8 +1047,9 @@ def test_groupnorm_writes_the_winograd_input_transform():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.2e-2)])
 @pytest.mark.parametrize("fr", [8, 32])
-def test_tattn_fused_with_output_projection_other_frame_counts(fr):
+def test_tattn_fused_with_output_projection_other_frame_counts(fr, dt, tol):
     """ca_tattn_fused with the output stage for 8 frames (BASELINE config 1: two pixels per MFMA row tile, the cross-pixel quarter of the
     scores masked) and 32 frames (config 5: two row tiles per pixel, 2 x 2 score blocks) -- against fp32 torch (motion_module.py:251-331,
     212-224) and against the unfused path (folded q|k|v GEMM, attention over the frames, output projection)."""
@@ -1056,7 +1057,6 @@ def test_tattn_fused_with_output_projection_other_frame_counts(fr):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import tattn_check as T
     from controlanimate_amd import kernels as K
-    dt = torch.float16
     for (b, tokens, lda, res) in [(2, 4096 * 16 // fr // 2, 320, True), (1, 2048 + 128 // fr * 3, 640, True), (2, 2048, 320, False)]:
         x, w, gamma, beta, pe = T.make(b, tokens, dt, lda=lda, fr=fr)
         wo, bo = T.make_out(dt)
@@ -1069,7 +1069,7 @@ def test_tattn_fused_with_output_projection_other_frame_counts(fr):
         assert y is not None and labels == ["tattn_out128"], (labels, b, tokens)
         assert torch.equal(y, T.fused_out(x, w, gamma, beta, pe, b, tokens, wo, bo, residual=res, fr=fr))
         rel = ((y.float() - ref).norm() / ref.norm()).item()
-        assert torch.isfinite(y.float()).all() and rel < 2e-3, (fr, b, tokens, rel)
+        assert torch.isfinite(y.float()).all() and rel < tol, (fr, b, tokens, rel)
         # the unfused path on the same operands: folded q|k|v GEMM + attention_temporal + to_out
         xc = x.contiguous()
         wf = (w.float() * gamma[None, :]).to(dt)
