@@ -24,7 +24,8 @@
 // input pixels.
 
 // Timing-only ablations (never in a shipped library: results are wrong): -DCA_PQ_ABLATE=bits, 1 = no global -> LDS units after
-// a block's first two, 2 = no fragment reads, 4 = no MFMAs, 8 = no barriers inside the K loop.
+// a block's first two, 2 = no fragment reads, 4 = no MFMAs, 8 = no barriers inside the K loop, 16 = every tile streams the operands of
+// tile (0, 0) (the stream then comes out of L2: what the latency of the Infinity Cache costs).
 #ifdef CA_PQ_ABLATE
 #define CA_PQ_ABL(bit) (((CA_PQ_ABLATE) & (bit)) != 0)
 #else
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pq(GemmKParams p, int tiles_tot
   };
 
   auto dma_set_tile = [&](int seq, int m0, int n0) __attribute__((always_inline)) {
+    if (CA_PQ_ABL(16)) m0 = 0, n0 = 0;
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));  // (opaque: hipcc would hoist the lane-dependent parts out of the tile loop and spill them)
     const int r8 = lane_o >> 3, cp = lane_o & 7;

@@ -9,7 +9,7 @@ Build one library per ablation (results of an ablated kernel are WRONG by constr
 
 bits: 1 = no global -> LDS units after a block's first two, 2 = no fragment reads (registers keep pseudo-random bit patterns:
 full-entropy operands, which by themselves slow the MFMAs down -- tools/gemm_data_power.py), 4 = no MFMAs, 8 = no barriers
-inside the K loop.  Results of round 3: DESIGN.md section 3.
+inside the K loop, 16 = every tile streams the operands of tile (0, 0) (an L2-resident stream: round 5).  Results of round 3: DESIGN.md section 3.
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +26,7 @@ def timeit(fn, it=20):
     return e0.elapsed_time(e1) / it
 tag = os.path.basename(os.environ.get("CA_HIP_LIB", "product"))
 out = []
-for (m, n, k) in [(32768, 640, 2560), (131072, 320, 1280), (32768, 1280, 1280)]:
+for (m, n, k) in [(32768, 640, 2560), (131072, 320, 1280), (32768, 1280, 1280), (8192, 10240, 1280), (32768, 5120, 640)]:
     a = torch.randn(m, k, device=DEV).half(); w = (torch.randn(n, k, device=DEV) * k ** -0.5).half(); b = torch.randn(n, device=DEV)
     K._plan_sink = lab = []; K.gemm(a, w, bias=b); K._plan_sink = None
     ms = timeit(lambda: K.gemm(a, w, bias=b))
