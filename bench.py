@@ -74,6 +74,9 @@ def parse():
                          "of CPU work and ~40 GB of host memory; measured once per host and cached in the temp directory; skipped by "
                          "itself when less than 48 GB of host memory are available)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short passes of BASELINE configs 1, 3, 4, 5 and bf16 config 2 that the default single-GPU config-2 run "
+                         "appends as `other_configs` (outside `value`; ~2 min)")
     ap.add_argument("--shapes", action="store_true", help="also print the per-shape GEMM/conv table (stderr)")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing (reported beside the metric)")
     ap.add_argument("--no-overlap", action="store_true", help="run the ControlNet stack on the main stream (no 2nd-stream overlap)")
@@ -600,17 +603,77 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}; they must agree")
     if args.plumbing_only:
         return plumbing_only(args)
-    from controlanimate_amd import kernels as K
     from controlanimate_amd import window_shard as WS
-    from controlanimate_amd.context import dispatch
     from tools import ab_switches
     switched_off = ab_switches.apply_from_env()  # (A/B runs only: the product has every form on and reads no environment)
     if switched_off:
         print(f"[bench] A/B run, switched off: {sorted(switched_off)}", file=sys.stderr)
+    rank, world, local_rank = WS.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    local_rank %= torch.cuda.device_count()  # (ranks may share a GPU in a gloo rehearsal run, CA_DIST_BACKEND=gloo)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    timer = KernelTimer()
+    if not args.no_roofline:
+        timer.install()
+    out = measure(args, timer, rank, world, device, headline=True)
+    if (rank == 0 and world == 1 and not args.no_other_configs and args.config == 2 and args.dtype == "fp16" and not args.no_roofline
+            and args.frames is None and args.size is None and args.controlnets is None):
+        out["other_configs"] = other_configs(args, timer, device)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(usable_cores())
+        if not args.no_cpu_baseline_config2:
+            out["cpu_baseline"]["config2_step"] = cpu_baseline_config2_cached(usable_cores())
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+OTHER_CONFIGS = (("config1", 1, "fp16"), ("config3", 3, "fp16"), ("config4", 4, "fp16"), ("config5", 5, "fp16"), ("config2_bf16", 2, "bf16"))
+
+
+def other_configs(args, timer, device):
+    """After the headline and OUTSIDE `value`: one short timed pass (5 loop iterations from a window start, after an untimed first
+    window that captures the hipGraph) of BASELINE configs 1, 3, 4, 5 and of config 2 in bf16 -- the product's loop, same calls as the
+    headline -- so that every configuration's ms per step, frames/s, MFMA fraction and dominant-kernel roofline are witnessed by
+    whoever runs the default command.  A configuration that fails reports its error and the others still run."""
+    import argparse as _ap
+    import gc
+    res = {}
+    for name, cfg, dt in OTHER_CONFIGS:
+        a = _ap.Namespace(**vars(args))
+        a.config, a.dtype, a.steps, a.warmup, a.no_vae, a.shapes = cfg, dt, min(5, int(CONFIGS[cfg]["steps"])), 2, True, False
+        t0 = time.perf_counter()
+        try:
+            o = measure(a, timer, 0, 1, device, headline=False)
+            roof = o.get("roofline") or {}
+            res[name] = {"workload": o["config"]["workload"], "dtype": dt, "steps": a.steps, "ms_per_step": o["ms_per_step"],
+                         "frames_per_sec": o["value"], "frames_per_sec_steady_state": o["frames_per_sec_steady_state"],
+                         "step_algorithmic_tflop": o["step_algorithmic_tflop"], "step_mfma_frac": o["step_mfma_frac"],
+                         "step_mfma_frac_algorithmic": o["step_mfma_frac_algorithmic"], "hip_graph": o["hip_graph"],
+                         "graph_replays_in_timed_region": o["graph_replays_in_timed_region"],
+                         "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches",
+                                                                "avg_launch_us", "share_of_step_time")} if roof else None,
+                         "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as exc:  # (never lose the headline line to a secondary configuration)
+            res[name] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return res
+
+
+def measure(args, timer, rank, world, device, headline=True):
+    """One configuration through the product's loop: models, untimed first window (eager step 0 + hipGraph capture), warm-up, the
+    timed K steps, the instrumented roofline pass.  Returns the JSON object (the caller adds the CPU baseline)."""
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd import window_shard as WS
+    from controlanimate_amd.context import dispatch
     from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
     from controlanimate_amd.schedulers import get_scheduler
     from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
-
+    timer.records, timer.other, timer.bytes, timer.enabled = [], [], {}, False
     wl = dict(CONFIGS[args.config])
     custom = False
     if args.frames is not None:
@@ -624,17 +687,7 @@ def main():
     scale = (wl["frames"] / base["frames"]) * (wl["height"] * wl["width"]) / (base["height"] * base["width"])  # (attention terms scale slightly faster)
     steps_per_window = wl["steps"]
 
-    rank, world, local_rank = WS.init_distributed()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    local_rank %= torch.cuda.device_count()  # (ranks may share a GPU in a gloo rehearsal run, CA_DIST_BACKEND=gloo)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-
-    timer = KernelTimer()
-    if not args.no_roofline:
-        timer.install()
     unet, nets = build_models(wl, device, dtype, rank)
     arenas = [unet.arena.buffer] + [n.arena.buffer for n in nets]
     bytes_bcast = WS.broadcast_weights(arenas)
@@ -815,6 +868,9 @@ def main():
         "host_cpu_ms_per_step": round(1e3 * host_cpu / args.steps, 3),
         "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
         "host_cpu_ms_per_step_by_thread": {k.split(":", 1)[1] + "#" + k.split(":", 1)[0]: round(1e3 * d / args.steps, 3) for d, k in host_threads},  # every thread that used CPU (at most 12; /proc granularity 10 ms over the region)
+        # CPU time the process total holds beyond every thread alive at the end of the region (threads that exited inside it)
+        "host_cpu_ms_per_step_unlisted": round(1e3 * (host_cpu - sum(th1[k] - th0.get(k, 0.0) for k in th1)) / args.steps, 3),
+        "host_intra_op_threads": {"inside_call": 1 if pipe.single_host_thread else torch.get_num_threads(), "process": torch.get_num_threads()},
         "steps_in_flight": int(pipe.steps_in_flight), "pace_wait": str(pipe.pace_wait),
         "step_algorithmic_tflop": round(step_tflop, 2),
         # utilisation of the dense MFMA peak by the work that was EXECUTED (the shared CFG prefix runs once: see below);
@@ -880,21 +936,17 @@ def main():
                                         "algorithmic_gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0,
                                         "rocprof_name": rocprof_kernel_name(k, args.dtype) or None,
                                         "time_share": round(v["ms"] * 1e-3 / roof_elapsed, 4)} for k, v in sorted(agg.items())}
-    if not args.no_roofline and world == 1 and "roofline" in out:
+    if headline and not args.no_roofline and world == 1 and "roofline" in out:
         out["roofline"]["matrix_rate_vs_operand_data"] = matrix_rate_vs_operand_data(dtype)
     if args.shapes and rank == 0 and not args.no_roofline:
         for row in timer.by_shape():
             print(row, file=sys.stderr)
         for row in timer.other_summary():
             print(row, file=sys.stderr)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(usable_cores())
-        if not args.no_cpu_baseline_config2:
-            out["cpu_baseline"]["config2_step"] = cpu_baseline_config2_cached(usable_cores())
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    # let go of everything this configuration holds on the device (the captured graph pins the models and their arenas)
+    pipe.release_graph()
+    timer.records, timer.other, timer.bytes = [], [], {}
+    return out
 
 
 if __name__ == "__main__":

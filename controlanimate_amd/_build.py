@@ -20,7 +20,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcontrolanimate_hip.so")
 SOURCES = ["ca_gemm.hip", "ca_gemm_pp.hip", "ca_gemm_ar.hip", "ca_norm.hip", "ca_attention.hip", "ca_elementwise.hip"]
 EXPERIMENT_HEADERS = [os.path.join("experiments", "ca_gemm_pp.h"), os.path.join("experiments", "ca_gemm_pp3.h")]  # -DCA_EXPERIMENTS builds only
-HEADERS = ["ca_common.h", "ca_gemm_core.h", "ca_gemm_pp2.h", "ca_gemm_wres.h", "ca_gemm_ps.h", "ca_gemm_pq.h", "ca_gemm_ar.h", "ca_ff_fused.h", "ca_attn_out.h", "ca_tattn_fused.h", "ca_xattn_fused.h", "ca_gemm_seq.h", os.path.join("..", "..", "include", "controlanimate_hip.h")]
+HEADERS = ["ca_common.h", "ca_gemm_core.h", "ca_gemm_pp2.h", "ca_gemm_wres.h", "ca_gemm_ps.h", "ca_gemm_pq.h", "ca_gemm_ar.h", "ca_ff_fused.h", "ca_attn_out.h", "ca_tattn_fused.h", "ca_xattn_fused.h", "ca_gemm_seq.h", "ca_conv_wino.h", os.path.join("..", "..", "include", "controlanimate_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          # keep MFMA accumulators in the (unified) VGPR file: without it hipcc parks them in AGPRs and the
          # attention kernel spends ~200 v_accvgpr_read/write per K/V tile on the softmax rescale

@@ -64,6 +64,7 @@ class MultiControlNetResidualsPipeline:
         self.annotators = {"canny": canny, **dict(annotators or {})}
         self.prep_images: Optional[List[torch.Tensor]] = None
         self.device = torch.device(device)
+        self.lanes_used = 0  # HIP streams the ControlNet bodies of the last residuals_nhwc_async call were spread over
 
     # ------------------------------------------------------------------------------------------
     def prepare_controlnet_input_image(self, controlnet_model: str, image):
@@ -139,6 +140,7 @@ class MultiControlNetResidualsPipeline:
         # vs 90.6 / 90.5 -- so two streams, from three nets on.
         nets = len(getattr(self.controlnet, "nets", ()))
         n_par = max(1, min(int(dispatch.controlnet_streams), nets)) if nets >= 3 else 1
+        self.lanes_used = n_par  # (what the last call really did: the tests of the multi-lane path assert on it)
         streams = [side]
         if n_par > 1:
             extra = getattr(self, "_extra_streams", None)

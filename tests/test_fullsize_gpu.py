@@ -320,6 +320,78 @@ def test_config2_step_repeats_bit_identically_with_the_controlnet_stream_beside_
     assert differing == 0, f"{differing} of 8 repeats differ from the first"
 
 
+def test_config3_step_four_full_width_controlnets_on_two_lanes_repeats_bit_identically():
+    """BASELINE config 3 at full size, as the product runs it: four full-width ControlNets whose bodies run
+    on two HIP streams beside the UNet encoder (16 frames, 64x64 latents, CFG batch 2), joined for the zero convolutions with the
+    residual adds fused -- eight repeats eagerly and eight replays of ONE captured hipGraph, every eps equal to the first bit
+    for bit, finite, the two CFG halves equal under identical conditioning, equal to the one-lane order, and the stack moves eps.
+    (/root/reference/modules/controlresiduals_pipeline.py:278-316 with SampleConfig.yaml's four nets.)"""
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.configs import controlnet_config, unet_config
+    from controlanimate_amd.context import dispatch
+    from controlanimate_amd.controlnet import ControlNetModel
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.unet import UNet3DConditionModel
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        unet = UNet3DConditionModel.from_config(unet_config("v2"))
+        nets = [ControlNetModel.from_config(controlnet_config()) for _ in range(4)]
+    for mod in (unet, *nets):
+        for p in mod.parameters():
+            if p.dim() > 1 and float(p.detach().abs().max()) == 0.0:
+                p.data.normal_(std=0.02)
+    unet.prepare(DEV, torch.float16)
+    for n in nets:
+        n.prepare(DEV, torch.float16)
+    f, hw = 16, 64
+    g = torch.Generator().manual_seed(19)
+    lat = torch.randn(1, 4, f, hw, hw, generator=g).to(DEV)
+    p1 = (torch.randn(1, 77, 768, generator=g) * 0.5).to(DEV)
+    prompt = torch.cat([p1, p1]).contiguous()   # both halves conditioned identically
+    cn = MultiControlNetResidualsPipeline(list("abcd"), [1.0, 0.8, 0.6, 0.4], use_lcm=False, controlnets=nets, device=DEV)
+    cn.prep_control_images({k: [h for h in torch.rand(f, 3, 512, 512, generator=g)] for k in "abcd"},
+                           do_classifier_free_guidance=True, guess_mode=False)
+    x2 = K.latents_to_nhwc(lat, unet.conv_in.cin_pad, 2, 1.0, torch.float16)
+    t = torch.full((1,), 481.0, device=DEV)
+
+    def enqueue():
+        down = cn.residuals_nhwc_async(x2, t, prompt, False, cfg_identical_halves=True, fuse_images=x2.shape[0])
+        return unet.forward_nhwc(x2, 2, f, t, prompt, down, None, cfg_identical_halves=True)
+
+    def step():
+        eps = enqueue()
+        torch.cuda.synchronize()
+        return eps.clone()
+
+    assert dispatch.controlnet_streams == 2
+    first = step()
+    assert cn.lanes_used == 2
+    assert torch.isfinite(first).all() and torch.equal(first[:f], first[f:])
+    differing = sum(int(not torch.equal(step(), first)) for _ in range(8))
+    assert differing == 0, f"{differing} of 8 eager repeats differ from the first"
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eps_static = enqueue()
+    bad = 0
+    for _ in range(8):
+        eps_static.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(eps_static, first))
+    assert bad == 0, f"{bad} of 8 replays of the captured two-lane step differ from the eager step"
+    del graph, eps_static
+    dispatch.controlnet_streams = 1
+    try:
+        one_lane = step()
+        assert cn.lanes_used == 1
+    finally:
+        dispatch.controlnet_streams = 2
+    assert torch.equal(one_lane, first), "four bodies on two streams differ from four bodies on one"
+    no_cn = unet.forward_nhwc(x2, 2, f, t, prompt, None, None, cfg_identical_halves=True)
+    torch.cuda.synchronize()
+    assert rel(no_cn, first) > 1e-3   # the four nets really contribute
+
+
 def test_config1_shape_v2_full_width_winograd_paths_agree():
     """BASELINE config 1's shape (8 frames, 32x32 latents: levels 32, 16, 8, 4) on the full-width mm-v2 UNet3D: the 8x8- and 16x16-latent
     convolutions take the Winograd route (with the GroupNorm writing the transformed input where it can), the 4x4 level -- 64 tiles --

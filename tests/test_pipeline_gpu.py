@@ -41,7 +41,7 @@ def build(version, seed, n_controlnets=0, ip=False, **over):
 
 
 def run_both(ucfg, uw, unet, ccfg, cws, nets, *, scheduler, steps, guidance, strength=1.0, use_lcm=False, guess_mode=False,
-             cond_scale=None, f=8, hw=8, seed=0, use_ip=False, ip_tokens=None, ip_oracle=None):
+             cond_scale=None, f=8, hw=8, seed=0, use_ip=False, ip_tokens=None, ip_oracle=None, tweak=None, want_ref=True):
     from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
     from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
     from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
@@ -63,6 +63,9 @@ def run_both(ucfg, uw, unet, ccfg, cws, nets, *, scheduler, steps, guidance, str
             def get_image_embeds_4controlanimate(self, pil_image=None, scale=0.4, clip_image_embeds=None):
                 return ip_tokens
         pipe.ip_adapter = _IP()
+    if tweak is not None:
+        tweak(pipe, cn)
+    run_both.last = (pipe, cn)
     lat_steps = []
     gen = torch.Generator(device="cpu").manual_seed(seed)
     torch.manual_seed(seed)
@@ -73,6 +76,8 @@ def run_both(ucfg, uw, unet, ccfg, cws, nets, *, scheduler, steps, guidance, str
                output_type="latent", callback=lambda i, t, l: lat_steps.append(l.clone()),
                clip_image_embeds=torch.zeros(1, 1024) if (use_ip and ip_tokens is not None) else None).videos
     torch.cuda.synchronize()
+    if not want_ref:
+        return out, None, lat_steps
 
     # ---- the oracle, fed with the same random draws
     gen = torch.Generator(device="cpu").manual_seed(seed)
@@ -180,3 +185,57 @@ def test_remaining_schedulers_of_the_reference_table(scheduler, steps):
     out, ref, errs = run_both(*parts, scheduler=scheduler, steps=steps, guidance=1.5)
     print(scheduler, "per-step latent rel_l2:", ["%.2e" % e for e in errs])
     assert len(errs) == len(ref["latents"]) and errs[0] < 1e-2 and max(errs) < 3e-2, errs
+
+
+def test_config3_four_controlnets_on_two_lanes_through_the_product_loop():
+    """BASELINE config 3's PRODUCT path: a stack of four ControlNets whose bodies are spread over two HIP
+    streams (`dispatch.controlnet_streams`, controlresiduals_pipeline.residuals_nhwc_async), joined on the side stream for the
+    zero convolutions with the 13 residual adds fused, eager at step 0 and inside the captured hipGraph from step 1 on --
+    through ControlAnimationPipeline.__call__ with the reference's non-guess CFG behaviour and the Euler sampler
+    (/root/reference/modules/controlresiduals_pipeline.py:30-38,278-316, configs/prompts/SampleConfig.yaml:59-68).
+    (a) against the fp32 oracle loop: raw eps of step 0 (identical inputs) within north_star's 1e-2, latents of every step;
+    (b) bit-equal, step by step, to the same call with the four bodies on ONE stream;  (c) the two lanes and the graph
+    replays really happened."""
+    from controlanimate_amd.context import dispatch
+    parts = build("v2", seed=33, n_controlnets=4)
+    scales = [1.0, 0.8, 0.6, 0.4]
+    kw = dict(scheduler="EulerDiscreteScheduler", steps=4, guidance=2.0, cond_scale=scales, seed=3)
+
+    def product(pipe, cn):
+        assert pipe.overlap_controlnet and pipe.fuse_controlnet_adds and pipe.use_hip_graph  # the defaults ARE the product
+        pipe.record_eps = True
+
+    assert dispatch.controlnet_streams == 2
+    out2, ref, errs = run_both(*parts, tweak=product, **kw)
+    pipe2, cn2 = run_both.last
+    assert cn2.lanes_used == 2 and len(cn2._extra_streams) == 1, cn2.lanes_used
+    assert pipe2.graph_fallback_reason is None and pipe2.graph_replays == 3, (pipe2.graph_replays, pipe2.graph_fallback_reason)
+    eps0 = pipe2.eps_history[0]
+    r0 = rel(eps0, ref["eps_raw"][0])
+    print("config-3 product loop: eps(step 0) rel_l2 = %.3e; per-step latent rel_l2:" % r0, ["%.2e" % e for e in errs])
+    assert r0 < 1e-2, r0
+    assert len(errs) == 4 and errs[0] < 1e-2 and errs[-1] < 4e-2, errs
+    lat2 = [l.clone() for l in _steps_of(parts, kw, product)]
+    dispatch.controlnet_streams = 1
+    try:
+        def single(pipe, cn):
+            product(pipe, cn)
+        lat1 = [l.clone() for l in _steps_of(parts, kw, single)]
+        assert run_both.last[1].lanes_used == 1
+    finally:
+        dispatch.controlnet_streams = 2
+    assert len(lat1) == len(lat2) == 4
+    for k, (a, b) in enumerate(zip(lat1, lat2)):
+        assert torch.isfinite(b).all() and torch.equal(a, b), f"two lanes differ from one lane after step {k}"
+    # ... and all-eager (no capture) agrees with the captured two-lane run as well
+    def eager(pipe, cn):
+        pipe.use_hip_graph = False
+    lat_e = _steps_of(parts, kw, eager)
+    assert run_both.last[0].graph_replays == 0 and run_both.last[1].lanes_used == 2
+    for k, (a, b) in enumerate(zip(lat_e, lat2)):
+        assert torch.equal(a, b), f"eager two-lane run differs from the captured one after step {k}"
+
+
+def _steps_of(parts, kw, tweak):
+    _, _, steps = run_both(*parts, tweak=tweak, want_ref=False, **kw)
+    return steps
