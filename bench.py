@@ -838,6 +838,11 @@ def measure(args, timer, rank, world, device, headline=True):
         rows_half, n_tok = f * (wl["height"] // 8) * (wl["width"] // 8), (wl["height"] // 8) * (wl["width"] // 8)
         one = (2 * 2.0 * rows_half * 320 * 2880 + 2.0 * rows_half * 320 * 1600 + 4.0 * n_tok * n_tok * 320 * f) * 1e-12
         shared_tflop = one * (1 + (0 if cn_single else len(nets)))  # UNet + every ControlNet that sees both halves
+    # non-guess CFG with an even frame count: the reference's prompt tiling makes the two halves of the ControlNet's batch the same
+    # problem end to end (controlnet.py forward_body) -- each net runs on one half: half of its algorithmic work is not executed
+    cn_dedup = bool(nets) and rep == 2 and not cn_single and dispatch.cn_cfg_dedup and f % 2 == 0
+    if cn_dedup:
+        shared_tflop = shared_tflop - one * len(nets) + 0.5 * cn_tflop * len(nets)
     f_new = f - wl["overlap"]
     out = {
         "metric": "frames_per_sec", "value": round(fps, 4), "unit": "frames/s",
@@ -882,6 +887,7 @@ def measure(args, timer, rank, world, device, headline=True):
         # computation, which runs once (bit-identical results: tests/test_workload_configs_gpu.py; CA_CFG_SHARED=0 disables it for an A/B run).  The
         # algorithmic count above is the reference's, which computes both halves; this is what was executed.
         "cfg_shared_prefix": bool(shared_tflop > 0),
+        "controlnet_cfg_halves_deduplicated": cn_dedup,
         "step_executed_tflop": round(step_tflop - shared_tflop, 2),
         "vae": None if vae_ms is None else {
             **vae_ms,

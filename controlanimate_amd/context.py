@@ -44,6 +44,7 @@ class Dispatch:
     repeat_kernel = True  # ca_repeat instead of torch.cat for the CFG-shared prefix
     ln_fold = True        # LayerNorm folded into the projection it feeds
     cfg_shared = True     # the prompt-independent prefix of the two CFG halves runs once
+    cn_cfg_dedup = True   # ControlNet under non-guess CFG: the reference's prompt tiling makes its two batch halves the same problem -- solved once
     controlnet_streams = 2  # HIP streams the bodies of a stack of >= 3 ControlNets are spread over (independent up to the summed residuals)
 
 

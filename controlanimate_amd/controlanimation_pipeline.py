@@ -248,10 +248,17 @@ class ControlAnimationPipeline:
             ev.synchronize()
             return
         nap, t0 = float(self.pace_poll_s), time.monotonic()
+        limit = float(self.pace_timeout_s) * max(1, int(self.steps_in_flight))  # (the awaited event sits behind that many steps)
         while not ev.query():
             time.sleep(nap)
-            if time.monotonic() - t0 > self.pace_timeout_s:  # a device hang must not become a silent endless poll
-                raise RuntimeError(f"the denoise step recorded {self.pace_timeout_s:.0f} s ago has not finished (device hang?)")
+            if time.monotonic() - t0 > limit:  # a device hang must not become a silent endless poll
+                # the work recorded before the event is still queued: nothing of this pipeline may be reused as it is -- the pacing
+                # ring's events (a later call would wait on them out of order), the captured graph and the noise buffers in flight
+                self.__dict__.pop("_pace_ring", None)
+                self._graph_state = None
+                self._noise_state = None
+                raise RuntimeError(f"the denoise step recorded {limit:.0f} s ago has not finished (device hang? serialised profiling and many "
+                                   f"ranks on one GPU stretch a step: raise `pace_timeout_s`, now {self.pace_timeout_s:.0f} s per step in flight)")
 
     def _pace_event(self, i: int):
         """Events of the pacing ring (created once: an event per step would be 20 create / destroy pairs per window).  Plain events for

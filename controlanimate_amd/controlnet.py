@@ -163,7 +163,8 @@ class ControlNetModel(HipModelMixin, nn.Module):
     @torch.no_grad()
     def forward_body(self, x: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
                      conditioning_scale: float = 1.0, guess_mode: bool = False, cfg_identical_halves: bool = False):
-        """Everything up to the zero convolutions: -> (the 12 block outputs, the mid-block output, the 13 residual scales)."""
+        """Everything up to the zero convolutions: -> (the 12 block outputs, the mid-block output, the 13 residual scales, `twice`);
+        twice = the outputs hold one of two identical CFG halves (see below) and apply_zero_convs writes the residuals for both."""
         device = x.device
         self._ensure_ready(device)
         images = x.shape[0]
@@ -179,8 +180,25 @@ class ControlNetModel(HipModelMixin, nn.Module):
         # halves are identical up to the first cross-attention -- see UNet3DConditionModel.forward_nhwc
         first = self.down_blocks[0]
         from .context import dispatch
-        shared = (cfg_identical_halves and dispatch.cfg_shared and images % 2 == 0 and bool(getattr(self, "_hint_doubled", False)) and
-                  getattr(first, "has_cross_attention", False) and (not torch.is_tensor(timestep) or timestep.numel() == 1))
+        same_inputs = (cfg_identical_halves and images % 2 == 0 and bool(getattr(self, "_hint_doubled", False)) and
+                       (not torch.is_tensor(timestep) or timestep.numel() == 1))
+        # The reference tiles the ControlNet's prompt as torch.cat([embeds] * frame_count) (modules/controlresiduals_pipeline.py:292,
+        # SURVEY App. C-1): image z of the (b f) batch reads embeds[z % nb].  With an even number of frames per CFG half
+        # ((images / 2) % nb == 0) image z and image z + images / 2 therefore read the SAME prompt row -- and under classifier-free
+        # guidance they also hold the same latents (reference :797), the same control frame (:268-269) and the same timestep: the two
+        # halves of the ControlNet's batch are the same problem from conv_in to the mid block.  It is solved once (half the batch, half of
+        # the ControlNet's work); the zero convolutions write its residuals for both halves (apply_zero_convs, `twice`).
+        if same_inputs and dispatch.cn_cfg_dedup and (images // 2) % nb == 0:
+            half = images // 2
+            hctx = dataclasses.replace(ctx, b=half)
+            x = self.conv_in.run(x[:half], residual=hint[:half])
+            outs = [x]
+            for blk in self.down_blocks:
+                x, o = blk(x, hctx)
+                outs += o
+            x = self.mid_block(x, hctx)
+            return outs, x, self.residual_scales(conditioning_scale, guess_mode), True
+        shared = same_inputs and dispatch.cfg_shared and getattr(first, "has_cross_attention", False)
         if shared:
             half = images // 2
             xh = self.conv_in.run(x[:half], residual=hint[:half])
@@ -194,22 +212,30 @@ class ControlNetModel(HipModelMixin, nn.Module):
             x, o = blk(x, ctx)
             outs += o
         x = self.mid_block(x, ctx)
-        return outs, x, self.residual_scales(conditioning_scale, guess_mode)
+        return outs, x, self.residual_scales(conditioning_scale, guess_mode), False
 
     @torch.no_grad()
-    def apply_zero_convs(self, outs, x, scales, accumulate: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None):
+    def apply_zero_convs(self, outs, x, scales, accumulate: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None, twice: bool = False):
         """The 13 zero convolutions: residual_i = scale_i * (zc_i(out_i)) [+ accumulate_i].  `accumulate` holds the running sums
         of the previous nets -- or, for the first net of a fused step, the UNet's own skip tensors and mid-block output
         (reference unet.py:567-576, 584-585: `sample + residual`): the add then happens in this GEMM's epilogue and the
-        result IS the tensor the UNet's up blocks consume."""
-        down = []
-        for i, (zc, o) in enumerate(zip(self.controlnet_down_blocks, outs)):
+        result IS the tensor the UNet's up blocks consume.
+        twice: `outs` / `x` hold ONE of the two identical CFG halves (forward_body's de-duplicated batch); the residuals are written
+        for both -- each half its own launch, on top of its own half of `accumulate`."""
+        def one(zc, o, scale, prev):
             B_, h, w, c = o.shape
-            prev = None if accumulate is None else accumulate[0][i].view(B_ * h * w, c)
-            down.append(zc.run(o.view(B_ * h * w, c), alpha=scales[i], residual=prev).view(B_, h, w, c))
-        B_, h, w, c = x.shape
-        prev = None if accumulate is None else accumulate[1].view(B_ * h * w, c)
-        mid = self.controlnet_mid_block.run(x.view(B_ * h * w, c), alpha=scales[-1], residual=prev).view(B_, h, w, c)
+            rows = B_ * h * w
+            a = o.view(rows, c)
+            if not twice:
+                return zc.run(a, alpha=scale, residual=None if prev is None else prev.view(rows, c)).view(B_, h, w, c)
+            full = torch.empty((2 * B_, h, w, c), device=o.device, dtype=o.dtype)
+            for hf in range(2):
+                zc.run(a, alpha=scale, residual=None if prev is None else prev.view(2 * rows, c)[hf * rows:(hf + 1) * rows],
+                       out=full.view(2 * rows, c)[hf * rows:(hf + 1) * rows])
+            return full
+        down = [one(zc, o, scales[i], None if accumulate is None else accumulate[0][i])
+                for i, (zc, o) in enumerate(zip(self.controlnet_down_blocks, outs))]
+        mid = one(self.controlnet_mid_block, x, scales[-1], None if accumulate is None else accumulate[1])
         return down, mid
 
     @torch.no_grad()
@@ -218,9 +244,9 @@ class ControlNetModel(HipModelMixin, nn.Module):
                      accumulate: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None, cfg_identical_halves: bool = False):
         """x: [B,h,w,cin_pad] activation dtype. Returns (12 NHWC residuals, mid), already scaled and --
         if `accumulate` holds the running sums of previous nets -- added to them."""
-        outs, xm, scales = self.forward_body(x, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, guess_mode,
-                                             cfg_identical_halves)
-        return self.apply_zero_convs(outs, xm, scales, accumulate)
+        outs, xm, scales, twice = self.forward_body(x, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, guess_mode,
+                                                    cfg_identical_halves)
+        return self.apply_zero_convs(outs, xm, scales, accumulate, twice)
 
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
                 conditioning_scale: float = 1.0, class_labels=None, timestep_cond=None, attention_mask=None,
@@ -272,8 +298,8 @@ class MultiControlNetModel(nn.Module):
     def finish(self, bodies, base: Optional[Tuple[List[torch.Tensor], torch.Tensor]] = None):
         """Zero convolutions of every net, summed -- on top of `base` = (the UNet's skips, its mid-block output) when given."""
         acc = base
-        for net, (outs, xm, scales) in zip(self.nets, bodies):
-            acc = net.apply_zero_convs(outs, xm, scales, acc)
+        for net, (outs, xm, scales, twice) in zip(self.nets, bodies):
+            acc = net.apply_zero_convs(outs, xm, scales, acc, twice)
         return acc
 
     def forward_nhwc(self, x, timestep, encoder_hidden_states, controlnet_cond: Sequence[torch.Tensor],

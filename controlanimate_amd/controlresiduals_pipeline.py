@@ -155,7 +155,7 @@ class MultiControlNetResidualsPipeline:
             for s_ in streams[1:]:
                 side.wait_stream(s_)
             if not capturing and n_par > 1:
-                for i, (outs_, xm_, _) in enumerate(bodies):
+                for i, (outs_, xm_, _, _) in enumerate(bodies):
                     if i % n_par:  # produced on another stream, read by the zero convolutions on `side`
                         for t_ in (*outs_, xm_):
                             t_.record_stream(side)

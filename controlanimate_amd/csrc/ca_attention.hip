@@ -17,7 +17,7 @@
 #define CA_ATTN_SETPRIO 0  // measured: no gain on this kernel (1.67 vs 1.61 ms)
 #endif
 
-int ar_cu_count();
+__attribute__((visibility("hidden"))) int ar_cu_count();  // (library-internal: not part of the C ABI)
 
 namespace {
 

@@ -4,7 +4,7 @@
 
 // CU count of the CURRENT device, cached per device id (a process may drive devices with different CU counts -- partition
 // modes -- and first calls may race: the slots are written once each with the same value, atomically).
-int ar_cu_count() {
+__attribute__((visibility("hidden"))) int ar_cu_count() {
   static std::atomic<int> cache[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;

@@ -341,6 +341,9 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, *, x2: Optional[torch.Tensor] = No
     return y
 
 
+_gn_wino_declined: dict = {}  # shapes group_norm_conv3x3_wino has declined (the library's answer depends on nothing else)
+
+
 def group_norm_conv3x3_wino(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor, w_wino: torch.Tensor, *,
                             x2: Optional[torch.Tensor] = None, groups: int = 32, eps: float = 1e-5, act: int = ACT_NONE,
                             bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None, rows_per_group: int = 0,
@@ -358,26 +361,34 @@ def group_norm_conv3x3_wino(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Te
     c2 = 0 if x2 is None else x2.shape[3]
     c, cout = c1 + c2, w.shape[0]
     tiles = images * (h // 2) * (w_ // 2)
-    y = torch.empty((images, h, w_, cout), device=x.device, dtype=x.dtype)
-    v = torch.empty((16, tiles, c), device=x.device, dtype=x.dtype)
-    cargs = ConvArgs(x=_p(v), x2=None, w=_p(w), y=_p(y), bias=_p(bias), rowbias=_p(rowbias), residual=_p(residual),
+    # the cheap declines first (the probes only need non-null pointers: x stands in for V and y until both sides have accepted;
+    # the decision is remembered per shape, so a resnet whose level the route declines costs two dictionary look-ups per eager step)
+    key = (images, h, w_, c1, c2, cout, groups, act, rowbias is not None, residual is not None, rows_per_group)
+    if _gn_wino_declined.get(key):
+        return None
+    cargs = ConvArgs(x=_p(x), x2=None, w=_p(w), y=_p(x), bias=_p(bias), rowbias=_p(rowbias), residual=_p(residual),
                      ld_res=cout if residual is not None else 0, ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, images=images, hin=h,
                      win=w_, cin1=c, cin2=0, cout=cout, stride=1, upsample=0, rows_per_group=rows_per_group, alpha=1.0, post_scale=post_scale,
                      act=ACT_NONE, out_f32=0, dtype=dt_code(x.dtype), pad_asym=0, w_wino=_p(w_wino), x_is_wino_v=1)
     # would the convolution take the Winograd route (given enough workspace)?  ca_conv3x3_workspace_bytes alone cannot tell: it also
     # answers > 0 for the split-K plan of a shape the route declines
-    cargs.workspace, cargs.workspace_bytes = _p(v), 1 << 60
+    cargs.workspace, cargs.workspace_bytes = _p(x), 1 << 60
     buf = C.create_string_buffer(64)
     if lib().ca_conv3x3_plan_name(C.byref(cargs), buf, 64) != 0 or not buf.value.decode().startswith("wino"):
+        _gn_wino_declined[key] = True
         return None
     wbytes = int(lib().ca_conv3x3_workspace_bytes(C.byref(cargs)))
     gargs = GroupNormArgs(x=_p(x), x2=_p(x2), y=None, gamma=_p(gamma), beta=_p(beta), partials=None, images=images, hw=h * w_, c1=c1, c2=c2,
-                          groups=groups, frames_per_stat=1, eps=eps, act=act, dtype=dt_code(x.dtype), wino_v=_p(v), wino_h=h, wino_w=w_)
+                          groups=groups, frames_per_stat=1, eps=eps, act=act, dtype=dt_code(x.dtype), wino_v=_p(x), wino_h=h, wino_w=w_)
     if wbytes <= 0 or not lib().ca_groupnorm_wino_supported(C.byref(gargs)):
+        _gn_wino_declined[key] = True
         return None
+    y = torch.empty((images, h, w_, cout), device=x.device, dtype=x.dtype)
+    v = torch.empty((16, tiles, c), device=x.device, dtype=x.dtype)
     if residual is not None:
         assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == y.numel()
     ws = torch.empty((wbytes,), device=x.device, dtype=torch.uint8)
+    cargs.x, cargs.y, gargs.wino_v = _p(v), _p(y), _p(v)
     cargs.workspace, cargs.workspace_bytes = _p(ws), wbytes
     if _plan_sink is not None:
         buf = C.create_string_buffer(64)

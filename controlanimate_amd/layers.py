@@ -203,7 +203,11 @@ class HipConv3x3(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels))
         nn.init.normal_(self.weight, std=(9 * in_channels) ** -0.5)
         self.w = self.b = None
-        self.winograd = True  # (False where the caller runs it with upsample / asymmetric padding: Upsample3D, the VAE's downsamplers)
+        # True: pack() also stores the Winograd form U of a deep stride-1 convolution.  Which CALLS take the route is the library's
+        # decision per shape (wino_workspace_bytes in ca_gemm.hip: >= 1280 input channels, or 640 .. 1279 at <= 4096 tiles -- 8-frame windows,
+        # the de-duplicated ControlNet batch -- nearest-x2 upsampling included, asymmetric padding and stride 2 not); a model that never
+        # reaches such a shape can set this False before prepare() and save 16/9 of the weight per convolution (VAE: never packed, < 640)
+        self.winograd = True
 
     def _packed_weight(self) -> torch.Tensor:
         w = _f32(self.weight).permute(0, 2, 3, 1)  # [Cout, kh, kw, Cin]

@@ -411,19 +411,33 @@ def run_video_sharded(config, frames: Sequence, components: Optional[dict] = Non
         ip = pipe.pipeline.ip_adapter
         tok_shape = (1, ip.num_tokens, int(pipe.pipeline.unet.config.cross_attention_dim))
         both = torch.zeros((2,) + tok_shape, device=device, dtype=torch.float32)
+        # the arguments are the same on every rank: a bad combination raises everywhere, before anybody waits in a collective
+        if image_prompt_embeds is not None and uncond_image_prompt_embeds is None:
+            raise ValueError("image_prompt_embeds needs uncond_image_prompt_embeds")
+        # rank 0 computes the fixed prompt (an initial denoising round, a CLIP encode); if that fails, the other ranks must not sit in
+        # the broadcast until the process-group timeout: a status word goes first and every rank raises together
+        status = torch.zeros(1, device=device, dtype=torch.float32)
+        failure = None
         if rank == 0:
-            if image_prompt_embeds is not None:
-                if uncond_image_prompt_embeds is None:
-                    raise ValueError("image_prompt_embeds needs uncond_image_prompt_embeds")
-                tok, untok = image_prompt_embeds, uncond_image_prompt_embeds
-            else:
-                image = ip_reference_image
-                if image is None:  # the reference's initial round (:199-203): window 0 without an image prompt, first frame = baseline
-                    s0, e0 = plan[0]
-                    image = pipe.animate(frames[s0:e0], None, cfg_of(0))[0]
-                tok, untok = ip.get_image_embeds_4controlanimate(pil_image=image, scale=float(_get(config, "ipa_scale", 0.4)))
-            both[0].copy_(tok.to(device).float().view(tok_shape))
-            both[1].copy_(untok.to(device).float().view(tok_shape))
+            try:
+                if image_prompt_embeds is not None:
+                    tok, untok = image_prompt_embeds, uncond_image_prompt_embeds
+                else:
+                    image = ip_reference_image
+                    if image is None:  # the reference's initial round (:199-203): window 0 without an image prompt, first frame = baseline
+                        s0, e0 = plan[0]
+                        image = pipe.animate(frames[s0:e0], None, cfg_of(0))[0]
+                    tok, untok = ip.get_image_embeds_4controlanimate(pil_image=image, scale=float(_get(config, "ipa_scale", 0.4)))
+                both[0].copy_(tok.to(device).float().view(tok_shape))
+                both[1].copy_(untok.to(device).float().view(tok_shape))
+            except Exception as exc:  # noqa: BLE001 -- re-raised below, on every rank
+                failure = exc
+                status.fill_(1.0)
+        WS.broadcast_tensor(status, src=0)
+        if float(status.item()) != 0.0:
+            if failure is not None:
+                raise failure
+            raise RuntimeError("rank 0 failed while preparing the fixed IP-Adapter image prompt (its traceback has the cause)")
         WS.broadcast_tensor(both, src=0)
         ip_kw = dict(image_prompt_embeds=both[0], uncond_image_prompt_embeds=both[1])
         run_video_sharded.last_image_prompt = both.cpu()

@@ -260,7 +260,7 @@ def test_fused_controlnet_adds_two_nets_within_rounding():
     sd, sm = cn.controlnet.finish(bodies, None)
     torch.cuda.synchronize()
     assert len(fd) == len(sd) == 12
-    d0, m0 = nets[0].apply_zero_convs(*bodies[0], None)  # the first net's term alone: the intermediate sums' magnitude
+    d0, m0 = nets[0].apply_zero_convs(*bodies[0][:3], None, bodies[0][3])  # the first net's term alone: the intermediate sums' magnitude
     for a, s_, r, r0 in zip((*fd, fm), (*base_d, base_m), (*sd, sm), (*d0, m0)):
         sep = K.add_bcast(s_, r)
         assert torch.isfinite(a).all() and r.float().abs().max() > 1e-3  # (the random zero convolutions are not zero)

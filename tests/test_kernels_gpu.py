@@ -944,6 +944,37 @@ def test_ff_fused_with_proj_out_c320(dtype):
 
 
 @pytest.mark.gpu
+def test_conv3x3_winograd_large_activations_stay_finite():
+    """The Winograd route keeps the transformed input V (sums of four activations) and the sixteen transformed products M in the
+    activation type, so its overflow headroom in fp16 is smaller than the direct form's.  Large-magnitude operands -- inputs
+    of std 24 (max ~ +-120, V up to 4x that), weights 4x the usual scale, outputs of std ~ 100 with a residual of the same size -- must
+    stay finite and within the direct form's distance of fp32 torch."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wino_check as W
+    k = _k()
+    for (images, h, c1, c2, cout) in [(32, 16, 1280, 1280, 1280), (32, 8, 1280, 0, 1280)]:
+        d = W.make(images, h, c1, c2, cout, epilogue=True, seed=11)
+        d["x"] = (d["x"].float() * 24.0).half()
+        if d["x2"] is not None:
+            d["x2"] = (d["x2"].float() * 24.0).half()
+        d["w32"] = d["w32"] * 4.0
+        d["w"] = d["w32"].permute(0, 2, 3, 1).contiguous().half()
+        d["u"] = torch.einsum("xk,oikl,yl->xyoi", W.G.to(DEV), d["w32"], W.G.to(DEV)).reshape(16, cout, c1 + c2).contiguous().half()
+        d["residual"] = (d["residual"].float() * 100.0).half()
+        k._plan_sink = labels = []
+        try:
+            y, direct = W.run(d, True), W.run(d, False)
+        finally:
+            k._plan_sink = None
+        assert labels[0] == "wino_pq256x320" and not labels[1].startswith("wino"), labels
+        ref = W.reference(d)
+        assert 50.0 < float(ref.std()) < 400.0 and float(ref.abs().max()) > 400.0   # (the operands really are large)
+        rel, rel_d = ((y.float() - ref).norm() / ref.norm()).item(), ((direct.float() - ref).norm() / ref.norm()).item()
+        assert torch.isfinite(y.float()).all() and torch.isfinite(direct.float()).all()
+        assert rel < 3e-3 and rel < 4 * rel_d + 1e-4, (rel, rel_d)
+
+
 def test_conv3x3_winograd():
     """The Winograd F(2x2, 3x3) route of ca_conv3x3 (ABI v12 w_wino, csrc/ca_conv_wino.h) on the shapes the plan gives it -- 16x16- and
     8x8-latent resnet convolutions, single input and the skip concatenations, with and without the resnet epilogue (bias, time-embedding

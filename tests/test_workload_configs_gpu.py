@@ -285,9 +285,14 @@ def test_shared_prefix_of_the_two_cfg_halves_changes_nothing():
     x2 = K.latents_to_nhwc(lat, unet.conv_in.cin_pad, 2, 1.0, torch.float16)
     cn = MultiControlNetResidualsPipeline(["a"], [0.8], use_lcm=False, controlnets=[net], device=DEV)
     cn.prep_control_images([x for x in torch.rand(f, 3, 8 * h, 8 * w, generator=g)], do_classifier_free_guidance=True, guess_mode=False)
+    from controlanimate_amd.context import dispatch
     d_full, m_full = cn.residuals_nhwc(x2, 500, prompt, False)
     d_full, m_full = [d.clone() for d in d_full], m_full.clone()
-    d_sh, m_sh = cn.residuals_nhwc(x2, 500, prompt, False, cfg_identical_halves=True)
+    dispatch.cn_cfg_dedup = False   # (the ControlNet's shared PREFIX: what runs when its two halves are not the same problem end to end)
+    try:
+        d_sh, m_sh = cn.residuals_nhwc(x2, 500, prompt, False, cfg_identical_halves=True)
+    finally:
+        dispatch.cn_cfg_dedup = True
     for k, (a, b) in enumerate(zip(d_full + [m_full], list(d_sh) + [m_sh])):
         assert torch.equal(a, b), f"ControlNet residual {k}"
     eps_full = unet.forward_nhwc(x2, 2, f, 500, prompt, d_full, m_full)
@@ -295,3 +300,51 @@ def test_shared_prefix_of_the_two_cfg_halves_changes_nothing():
     torch.cuda.synchronize()
     assert torch.isfinite(eps_sh).all() and torch.equal(eps_full, eps_sh)
     assert not torch.equal(eps_sh[:f], eps_sh[f:])   # (the halves do differ: different prompts)
+
+
+def test_controlnet_cfg_halves_are_one_problem_and_run_once():
+    """Non-guess classifier-free guidance: the reference tiles the ControlNet's prompt as torch.cat([embeds] * frame_count)
+    (/root/reference/modules/controlresiduals_pipeline.py:292: image z of the (b f) batch reads embeds[z % 2]), feeds both halves
+    the same latents (:797 of the pipeline) and the same control frames (:268-269) -- so with an even frame count image z and
+    image z + f are the same problem.  `dispatch.cn_cfg_dedup` solves it once and writes the residuals for both halves.  Checked
+    here at full width against the all-images run: both halves of the FULL run are bit-equal (the premise), the de-duplicated
+    residuals equal them to fp16 rounding (another batch size may pick another tile plan), its two halves are bit-equal, the
+    fused form adds each half of the UNet's skips to its own half, and an odd frame count (the premise fails) runs all images."""
+    from controlanimate_amd import kernels as K
+    from controlanimate_amd.context import dispatch
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    h, w = 32, 32
+    net = _full_controlnet(41, strip_ip=False)
+    g = torch.Generator().manual_seed(13)
+    neg, pos = ((torch.randn(1, 77, 768, generator=g) * 0.5).to(DEV) for _ in range(2))
+    prompt = torch.cat([neg, pos]).contiguous()
+    for f, expect_twice in ((6, True), (5, False)):
+        lat = torch.randn(1, 4, f, h, w, generator=g).to(DEV)
+        x2 = K.latents_to_nhwc(lat, net.conv_in.cin_pad, 2, 1.0, torch.float16)
+        cn = MultiControlNetResidualsPipeline(["a"], [0.8], use_lcm=False, controlnets=[net], device=DEV)
+        cn.prep_control_images([x for x in torch.rand(f, 3, 8 * h, 8 * w, generator=g)], do_classifier_free_guidance=True, guess_mode=False)
+        body = net.forward_body(x2, 500, prompt, cn.prep_images[0], 0.8, False, cfg_identical_halves=True)
+        assert body[3] is expect_twice and body[1].shape[0] == (f if expect_twice else 2 * f)
+        dispatch.cn_cfg_dedup = False
+        try:
+            d_all, m_all = cn.residuals_nhwc(x2, 500, prompt, False, cfg_identical_halves=True)
+            d_all, m_all = [d.clone() for d in d_all], m_all.clone()
+        finally:
+            dispatch.cn_cfg_dedup = True
+        d_one, m_one = cn.residuals_nhwc(x2, 500, prompt, False, cfg_identical_halves=True)
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(zip(d_all + [m_all], list(d_one) + [m_one])):
+            assert a.shape == b.shape and torch.isfinite(b).all()
+            if f % 2 == 0:
+                assert torch.equal(a[:f], a[f:]), f"residual {k}: the halves of the all-images run differ -- the premise is wrong"
+                assert torch.equal(b[:f], b[f:])
+            assert rel(b, a) < 3e-3, (k, rel(b, a))
+        if expect_twice:  # fused: out = zero_conv(half) + skips, each half of the skips to its own half of the result
+            outs, xm, scales, twice = body
+            skips = [(torch.randn(2 * o.shape[0], *o.shape[1:], generator=g) * 0.5).half().to(DEV) for o in outs]
+            mid_x = (torch.randn(2 * xm.shape[0], *xm.shape[1:], generator=g) * 0.5).half().to(DEV)
+            fd, fm = net.apply_zero_convs(outs, xm, scales, (skips, mid_x), twice)
+            pd, pm = net.apply_zero_convs(outs, xm, scales, None, twice)
+            torch.cuda.synchronize()
+            for a, s_, r in zip((*fd, fm), (*skips, mid_x), (*pd, pm)):
+                assert torch.equal(a, K.add_bcast(s_, r))   # (one net: the epilogue's add rounds like the separate add, test_graph_gpu.py)

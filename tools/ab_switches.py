@@ -19,6 +19,7 @@ ENV = {
     "CA_REPEAT_KERNEL": "repeat_kernel",
     "CA_LN_FOLD": "ln_fold",
     "CA_CFG_SHARED": "cfg_shared",
+    "CA_CN_DEDUP": "cn_cfg_dedup",
 }
 
 
