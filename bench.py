@@ -95,6 +95,10 @@ def parse():
                     help="multi-rank plumbing rehearsal WITHOUT the hot path (runs on a CPU box over gloo): rendezvous, "
                          "weight-arena broadcast, barriers, max-over-ranks timing, rank-0 JSON with `dry_run: true` and "
                          "`value: null`.  Never a measurement; used by tests/test_bench_launch.py")
+    ap.add_argument("--window-graph", action="store_true",
+                    help="ControlAnimationPipeline.window_graph: a whole window as ONE captured hipGraph, one replay per window, no per-step events (A/B; "
+                         "slower on ROCm 7.2 -- the launch cost of a graph grows with the square of its node count).  Default: one replay + three "
+                         "eager launches per STEP, a HIP event after every step")
     ap.add_argument("--pace-wait", default=None, choices=["sleep", "event"],
                     help="how the paced loop waits: hipEventQuery polls between naps (default) or a blocking hipEventSynchronize (A/B)")
     args = ap.parse_args()
@@ -214,7 +218,7 @@ def kernel_display_name(family: str) -> str:
     return f"k_gemm_dma<{family}>"
 
 
-PMC_SUMMARIES = ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
+PMC_SUMMARIES = ("round6_pmc_traffic.json", "round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
 
 
 def pmc_traffic(kernel_prefix: str, workload_key: str, dtype: str):
@@ -727,6 +731,8 @@ def measure(args, timer, rank, world, device, headline=True):
     pipe.use_hip_graph = not args.no_graph
     pipe.overlap_controlnet = not args.no_overlap
     pipe.fuse_controlnet_adds = not args.no_fuse_adds
+    pipe.window_graph = bool(args.window_graph)
+    per_step_events = not (args.window_graph and not args.no_graph)  # (a callback needs the host between steps: it selects the per-step path)
     if args.steps_in_flight is not None:
         pipe.steps_in_flight = args.steps_in_flight
     if args.pace_wait is not None:
@@ -745,7 +751,11 @@ def measure(args, timer, rank, world, device, headline=True):
         out = pipe(video_length=f, input_frames=None, height=wl["height"], width=wl["width"], num_inference_steps=steps_per_window,
                    strength=1.0, guidance_scale=guidance, generator=gen, latents=lat0, prompt_embeds=pos, negative_prompt_embeds=neg,
                    multicontrolnetresiduals_pipeline=cn, control_images=hints_dev, use_lcm=False, guess_mode=wl["guess_mode"],
-                   output_type="latent", step_range=(lo, hi), callback=cb).videos
+                   output_type="latent", step_range=(lo, hi), callback=cb if (per_step_events or timer.enabled) else None).videos
+        if record_events and not per_step_events:  # whole-window replay: one event at the end of the call's steps
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            step_events.append(("end", e, hi - lo))
         state["latents"] = out
         state["replays"] = state.get("replays", 0) + int(pipe.graph_replays)
         return out
@@ -769,7 +779,7 @@ def measure(args, timer, rank, world, device, headline=True):
     # first window, untimed: the eager step 0 (fills every cache, warms the allocator) and the capture at step 1
     run_steps(0, steps_per_window)
     torch.cuda.synchronize()
-    use_graph = bool(pipe.use_hip_graph) and pipe.graph_fallback_reason is None and pipe._graph_state is not None and pipe._graph_state["graph"] is not None
+    use_graph = bool(pipe.use_hip_graph) and pipe.graph_fallback_reason is None and pipe._graph_state is not None and (pipe._graph_state["graph"] is not None or bool(pipe._graph_state["wgraphs"]))
     if pipe.use_hip_graph and not use_graph:
         print(f"[bench] hipGraph capture failed ({pipe.graph_fallback_reason}); running eagerly", file=sys.stderr)
     # The timed region starts AT a window start: the warm-up steps are the last ones of the previous window.  K timed steps
@@ -796,7 +806,10 @@ def measure(args, timer, rank, world, device, headline=True):
     elapsed = time.perf_counter() - t0
     step_ms, prev = [], None
     for e in step_events:
-        if isinstance(e, tuple):
+        if isinstance(e, tuple) and e[0] == "start":
+            prev = e[1]
+        elif isinstance(e, tuple):  # ("end", event, steps): a call that ran as one replay -- its mean step
+            step_ms.append(prev.elapsed_time(e[1]) / max(1, e[2]))
             prev = e[1]
         else:
             step_ms.append(prev.elapsed_time(e))
@@ -866,6 +879,8 @@ def measure(args, timer, rank, world, device, headline=True):
                                             "uploaded, at every window start; the timed region begins at a window start" if use_graph else
                                             "eager run: nothing is cached outside the timed region except across the steps of a window"),
         "graph_replays_in_timed_region": int(replays_timed) if use_graph else 0,
+        "window_graph": bool(use_graph and pipe.window_graph and pipe.window_graph_fallback_reason is None and pipe.window_replays > 0),
+        "window_graph_fallback_reason": pipe.window_graph_fallback_reason,
         # host side of the product loop per step.  `host_cpu_ms_per_step` = CPU time of the process (all threads) while the K calls
         # ran: what N ranks on one host compete for.  `host_enqueue_ms_per_step` = wall time until the calls returned, before the
         # device synchronise: a replay of the captured graph waits for the previous replay of the same graph (measured: 2.3 ms on

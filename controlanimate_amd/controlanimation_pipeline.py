@@ -50,6 +50,18 @@ class ControlAnimationPipeline:
         # instead of ~50 ms of host time per step: with 8 ranks on one host the loop stays GPU-bound.  A failed capture is
         # logged and the window runs eagerly (`graph_fallback_reason`).
         self.use_hip_graph = True
+        # True: a WHOLE window -- every loop iteration: CFG duplicate, ControlNet stack, UNet3D, CFG combine + sampler update -- is
+        # ONE captured hipGraph, replayed once per window: the reference's loop (:792-855) has no host dependence between its steps
+        # either.  Each step's timestep, input scale and sampler coefficients are constants of its own kernel nodes; the sampler
+        # noise of the window is drawn and uploaded before the replay.  Taken when nothing needs the host between steps: no
+        # `callback`, no `record_eps`, a single-step sampler (the history-carrying ones keep the per-step graph) and a whole window
+        # (`step_range` unset or full); otherwise the per-step graph above.  Bit-identical latents (tests/test_graph_gpu.py).
+        # OFF by default, by measurement (round 6, ROCm 7.2, one box, config 2): hipGraphLaunch's host cost grows with the SQUARE of
+        # the node count -- 3 ms for the 786 kernels of one step, 1.1 s for the 15 720 of a 20-step window -- so the one-replay window
+        # is host-bound: 65.9 / 66.2 ms per step against 49.8 / 49.7 for twenty per-step replays (profiles/round6_ab_window_graph.json).
+        self.window_graph = False
+        self.window_graph_fallback_reason = None
+        self.window_replays = 0  # whole-window replays since construction (tests, bench)
         # How far the host may run ahead of the device, in denoise steps.  An unpaced loop enqueues faster than the device
         # drains (a replay is ~3 us of host time per kernel against ~75 us of device time), fills the hardware queue and then
         # SPINS inside the runtime for the rest of every step: two cores per rank for nothing (round 4: 122 ms of CPU per
@@ -403,6 +415,7 @@ class ControlAnimationPipeline:
         latents = latents.to(device=device, dtype=torch.float32).contiguous()
         f = latents.shape[2]
         step_range = kwargs.get("step_range")
+        whole = step_range is None or (step_range[0] == 0 and step_range[1] >= len(timesteps))  # the call covers the window's every step
         if step_range is not None:
             # parity-test hook ("teacher forcing"): run only loop iterations lo..hi-1 of the schedule, starting from the
             # given `latents` -- a step is then compared with the reference on IDENTICAL inputs
@@ -449,7 +462,7 @@ class ControlAnimationPipeline:
             gs = self._graph_state
             if gs is None or gs["sig"] != sig:
                 gs = self._graph_state = {
-                    "sig": sig, "graph": None, "eps": None, "owned": None,
+                    "sig": sig, "graph": None, "eps": None, "owned": None, "wgraphs": {}, "lat_in": None,
                     # the signature holds ids: keep the objects alive so that an id cannot be reused by another object
                     "keep": (unet, unet.arena, tuple(nets), tuple(n.arena for n in nets), cn,
                              tuple(cn.prep_images) if cn is not None else None),
@@ -463,12 +476,15 @@ class ControlAnimationPipeline:
             if w_embedding is not None:
                 gs["w"].copy_(w_embedding)
             unet_prompt, cn_prompt, w_embedding = gs["unet_prompt"], gs["cn_prompt"], gs["w"]
-            if gs["graph"] is not None and not self._graph_owns_model_caches(gs, unet, nets, cn):
+            captured = gs["graph"] is not None or bool(gs.get("wgraphs"))
+            if captured and not self._graph_owns_model_caches(gs, unet, nets, cn):
                 # an eager forward of the same models in between (another prompt tensor, a one-step call, a second pipeline
                 # sharing the UNet) replaced the caches the captured kernels read: their buffers may be freed or stale
                 logger.info("the models' per-window caches changed hands since the hipGraph was captured: capturing again")
                 gs["graph"] = gs["eps"] = gs["owned"] = None
-            if gs["graph"] is not None:  # a later window: the per-window caches (text / IP K/V, hint embeddings), in place
+                gs["wgraphs"] = {}
+                captured = False
+            if captured:  # a later window: the per-window caches (text / IP K/V, hint embeddings), in place
                 unet.refresh_window_caches()
                 for n_ in nets:
                     n_.refresh_window_caches()
@@ -522,6 +538,61 @@ class ControlAnimationPipeline:
 
         pace_n = int(self.steps_in_flight) if device.type == "cuda" else 0
         pace = []  # blocking events, one per step in flight (oldest first)
+
+        # ---- one replay per window ------------------------------------------------------------------------------------------
+        window_mode = (use_graph and bool(self.window_graph) and callback is None and not self.record_eps and whole
+                       and not getattr(sched, "multistep", False))
+        if window_mode:
+            plan = []
+            for i, t in enumerate(timesteps):
+                coef, clip = sched.coefficients(first + i)
+                plan.append((float(t), float(sched.input_scale(first + i)), tuple(float(c) for c in coef), float(clip)))
+            if needs_noise:
+                noise_all = draw_all_noise()  # host draw + asynchronous upload into the static device buffer the graph reads
+            g_eff = float(guidance_scale) if rep == 2 else 1.0
+            wkey = (tuple(plan), g_eff, bool(use_lcm), None if noise_all is None else noise_all.data_ptr())
+            if gs["lat_in"] is None or gs["lat_in"].shape != latents.shape:
+                gs["lat_in"] = torch.empty_like(latents)
+                gs["wgraphs"] = {}
+            gs["lat_in"].copy_(latents)
+            ent = gs["wgraphs"].get(wkey)
+            if ent is None:
+                try:
+                    # warm-up outside the capture: one eager evaluation fills the models' per-window caches and the allocator pools
+                    K.latents_to_nhwc(gs["lat_in"], cpad, rep, plan[0][1], unet.act_dtype, out=gs["x"])
+                    gs["t"].fill_(plan[0][0])
+                    model_eps(gs["x"], gs["t"])
+                    torch.cuda.synchronize()
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_):
+                        lat_k, den_k = gs["lat_in"], None
+                        for i, (t_k, scale_k, coef_k, clip_k) in enumerate(plan):
+                            K.latents_to_nhwc(lat_k, cpad, rep, scale_k, unet.act_dtype, out=gs["x"])
+                            gs["t"].fill_(t_k)
+                            eps_k = model_eps(gs["x"], gs["t"])
+                            lat_k, den_k = K.cfg_scheduler_step(eps_k, rep, g_eff, lat_k, noise_all[i] if needs_noise else None, coef_k, clip_k,
+                                                                want_denoised=use_lcm)
+                    ent = {"graph": g_, "out": lat_k, "den": den_k}
+                    if len(gs["wgraphs"]) >= 2:  # (a pipeline alternating more than two schedules: keep the two newest)
+                        gs["wgraphs"].pop(next(iter(gs["wgraphs"])))
+                    gs["wgraphs"][wkey] = ent
+                    gs["owned"] = self._model_cache_owners(unet, nets)
+                    self.window_graph_fallback_reason = None
+                except Exception as exc:  # never silent, never fatal: this window runs on the per-step path
+                    ent = None
+                    self.window_graph_fallback_reason = f"{type(exc).__name__}: {exc}"
+                    logger.warning("capturing the whole-window hipGraph failed (%s); per-step graph instead", self.window_graph_fallback_reason)
+                    torch.cuda.synchronize()
+            if ent is not None:
+                ent["graph"].replay()
+                self.graph_replays += 1
+                self.window_replays += 1
+                ev = self._pace_event(0)
+                ev.record()
+                self._await(ev)  # (sleeps until the window is done: the caller's next device read would otherwise spin in the runtime)
+                latents = ent["out"].clone()
+                denoised = None if ent["den"] is None else ent["den"].clone()
+                timesteps = timesteps[:0]  # the loop below has nothing left to do
         for i, t in enumerate(timesteps):
             idx = first + i
             in_scale = sched.input_scale(idx)

@@ -268,3 +268,92 @@ def test_fused_controlnet_adds_two_nets_within_rounding():
         scale = torch.stack(mags).amax(0).clamp_min(1e-3)
         ulps = ((a.float() - sep.float()).abs() / (scale * 2.0 ** -10)).max().item()
         assert ulps <= 3.0, ulps
+
+
+@pytest.mark.parametrize("scenario", ["lcm_cfg_controlnet", "native_lcm_guess", "euler_ancestral_cfg_two_controlnets"])
+def test_whole_window_graph_is_bit_identical_to_the_per_step_paths(scenario):
+    """ControlAnimationPipeline.window_graph (opt-in; applies when nothing needs the host between steps: no callback): every loop iteration
+    of a window -- CFG duplicate with the sampler's input scale, ControlNet stack on the side stream, UNet3D, CFG combine + sampler
+    update with the step's coefficients and its slice of the pre-uploaded noise -- is ONE captured hipGraph, replayed once per window
+    (/root/reference/animatediff/pipelines/controlanimation_pipeline.py:792-855 has no host dependence between steps either).
+    Three windows (new prompts, control frames and latents each; an eager forward with a foreign prompt between windows 2 and 3 forces
+    a re-capture) == the same windows on the per-step graph == all-eager, bit for bit; one replay per window."""
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+    from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
+    from controlanimate_amd.controlresiduals_pipeline import MultiControlNetResidualsPipeline
+    from controlanimate_amd.schedulers import get_scheduler
+    from tests.test_pipeline_gpu import build
+    native = scenario == "native_lcm_guess"
+    n_nets = 2 if scenario.endswith("two_controlnets") else 1
+    sched_name = "EulerAncestralDiscreteScheduler" if n_nets == 2 else "LCMScheduler"
+    ucfg, uw, unet, ccfg, cws, nets = build("v2", seed=81, n_controlnets=n_nets, **({"time_cond_proj_dim": 256} if native else {}))
+    f, hw, nsteps = 8, 8, 4
+    g = torch.Generator().manual_seed(39)
+    mk = lambda: dict(pos=torch.randn(1, 77, 768, generator=g) * 0.5, neg=torch.randn(1, 77, 768, generator=g) * 0.5,
+                      hints=torch.rand(f, 3, 8 * hw, 8 * hw, generator=g), lat=torch.randn(1, 4, f, hw, hw, generator=g) * 0.8)
+    windows, other = [mk() for _ in range(3)], mk()
+    names = [f"n{i}" for i in range(n_nets)]
+    runs = {}
+    for mode in ("eager", "per_step", "window"):
+        sched = None if native else get_scheduler(sched_name, **NOISE_SCHEDULER_KWARGS)
+        pipe = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched).to(DEV)
+        assert pipe.use_hip_graph is True and pipe.window_graph is False  # the defaults (window_graph: opt-in, see its comment)
+        pipe.use_hip_graph = mode != "eager"
+        pipe.window_graph = mode == "window"
+        cn = MultiControlNetResidualsPipeline(names, [0.8, 0.5][:n_nets], use_lcm=native, controlnets=nets, device=DEV)
+        torch.manual_seed(3)
+        gen = torch.Generator(device="cpu").manual_seed(3)
+        outs, replays = [], []
+        for k, w in enumerate(windows):
+            out = pipe(video_length=f, input_frames=None, height=8 * hw, width=8 * hw, num_inference_steps=nsteps, strength=0.5 if native else 1.0,
+                       guidance_scale=7.5 if native else 1.3, generator=gen, multicontrolnetresiduals_pipeline=cn, prompt_embeds=w["pos"],
+                       negative_prompt_embeds=w["neg"], use_lcm=native, guess_mode=native, input_latents=w["lat"],
+                       control_images={n: [h for h in w["hints"]] for n in names}, output_type="latent").videos
+            torch.cuda.synchronize()
+            outs.append(out.clone())
+            replays.append(pipe.graph_replays)
+            if k == 1:  # an intruder: the same models, another prompt -- the captured kernels' caches change hands
+                pr = torch.cat([other["neg"], other["pos"]]).to(DEV)
+                unet.forward_nhwc(torch.randn(2 * f, hw, hw, unet.conv_in.cin_pad, generator=g).half().to(DEV), 2, f, 500.0, pr, None, None)
+                torch.cuda.synchronize()
+        if mode == "window":
+            assert pipe.window_graph_fallback_reason is None and pipe.graph_fallback_reason is None
+            assert replays == [1, 1, 1] and pipe.window_replays == 3, (replays, pipe.window_replays)
+        elif mode == "per_step":
+            assert pipe.window_replays == 0 and all(r >= nsteps - 1 for r in replays), replays
+        runs[mode] = outs
+    for k in range(3):
+        assert torch.isfinite(runs["window"][k]).all()
+        assert torch.equal(runs["eager"][k], runs["per_step"][k]), f"per-step graph differs from eager in window {k}"
+        assert torch.equal(runs["eager"][k], runs["window"][k]), f"whole-window graph differs from eager in window {k}"
+    assert not torch.equal(runs["window"][0], runs["window"][1])
+
+
+def test_whole_window_graph_steps_aside_when_the_host_is_needed_between_steps():
+    """A `callback` (or `record_eps`, a history-carrying sampler, a partial `step_range`) needs the host between steps: such calls keep the
+    per-step graph, and a pipeline that alternates the two kinds of call keeps both captures alive."""
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+    from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
+    from controlanimate_amd.schedulers import get_scheduler
+    from tests.test_pipeline_gpu import build
+    ucfg, uw, unet, ccfg, cws, nets = build("v2", seed=83)
+    f, hw = 8, 8
+    g = torch.Generator().manual_seed(41)
+    pos, neg = torch.randn(1, 77, 768, generator=g) * 0.5, torch.randn(1, 77, 768, generator=g) * 0.5
+    lat = torch.randn(1, 4, f, hw, hw, generator=g)
+    pipe = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet,
+                                    scheduler=get_scheduler("DDIMScheduler", **NOISE_SCHEDULER_KWARGS)).to(DEV)
+    pipe.window_graph = True
+    kw = dict(video_length=f, input_frames=None, height=8 * hw, width=8 * hw, num_inference_steps=4, strength=1.0, guidance_scale=2.0,
+              prompt_embeds=pos, negative_prompt_embeds=neg, use_lcm=False, output_type="latent")
+    a = pipe(latents=lat.clone(), **kw).videos.clone()
+    assert pipe.window_replays == 1 and pipe.graph_replays == 1
+    seen = []
+    b = pipe(latents=lat.clone(), callback=lambda i, t, l: seen.append(i), **kw).videos.clone()
+    assert pipe.window_replays == 1 and len(seen) == 4 and pipe.graph_replays == 3   # eager step 0 + capture + 3 replays
+    c = pipe(latents=lat.clone(), **kw).videos.clone()
+    assert pipe.window_replays == 2 and pipe.graph_replays == 1                      # the window capture was kept
+    d = pipe(latents=lat.clone(), step_range=(1, 4), **kw).videos                    # (a partial window: per-step)
+    assert pipe.window_replays == 2
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.isfinite(d).all()

@@ -2,7 +2,7 @@
   * the union of all kernel intervals of a steady-state window of the trace (both streams): busy vs idle time of the GPU,
   * the gaps between consecutive kernels of the busier queue, by size class,
   * time during which exactly one / two (or more) kernels are in flight, and the kernels that most often run alone after a gap.
-    python tools/timeline_gaps.py <kernel_trace.csv> [steps_in_window]
+    python tools/timeline_gaps.py <kernel_trace.csv> [steps_in_window [steps_to_skip_at_the_end]]
 Steps are delimited by the launches of the temporal-attention kernel of the 64x64-latent level (10 per step of BASELINE config 2).
 """
 import csv
@@ -25,8 +25,11 @@ def main():
     marks = [s for s, e, n, q in rows if "k_tattn_out" in n or "k_tattn_fused" in n]
     per_step = 10
     nsteps = len(marks) // per_step
-    want = int(sys.argv[2]) if len(sys.argv) > 2 else min(10, nsteps - 6)
-    first = (nsteps - want - 2) * per_step  # a window near the end of the run: the timed, graph-replayed steps
+    # bench.py ends with an INSTRUMENTED pass (5 eager single-stream steps with an event pair around every GEMM launch) and probe
+    # launches: the window must end before them -- `skip_last` steps from the end (default 7), inside the timed, graph-replayed steps
+    skip_last = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+    want = int(sys.argv[2]) if len(sys.argv) > 2 else min(10, nsteps - skip_last - 4)
+    first = (nsteps - want - skip_last) * per_step
     t0, t1 = marks[first], marks[first + want * per_step]
     win = [(max(s, t0), min(e, t1), n, q) for s, e, n, q in rows if e > t0 and s < t1]
     span = (t1 - t0) / 1e6
