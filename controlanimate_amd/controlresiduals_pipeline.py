@@ -64,6 +64,7 @@ class MultiControlNetResidualsPipeline:
         self.annotators = {"canny": canny, **dict(annotators or {})}
         self.prep_images: Optional[List[torch.Tensor]] = None
         self.device = torch.device(device)
+        self.detect_identical_halves = True  # __call__ (the reference's own entry point) checks whether the two CFG halves of its input are equal
         self.lanes_used = 0  # HIP streams the ControlNet bodies of the last residuals_nhwc_async call were spread over
 
     # ------------------------------------------------------------------------------------------
@@ -201,7 +202,13 @@ class MultiControlNetResidualsPipeline:
         net0 = self.controlnets[0]
         net0._ensure_ready(control_model_input.device)
         x = K.ncfhw_to_nhwc(control_model_input, net0.conv_in.cin_pad, net0.act_dtype)
-        down, mid = self.residuals_nhwc(x, t, controlnet_prompt_embeds, guess_mode)
+        # The reference's loop hands over `torch.cat([latents] * 2)` under classifier-free guidance (controlanimation_pipeline.py:797-813):
+        # when the two halves really are the same tensor twice (one small device compare per call), the ControlNets may treat them as
+        # one problem (ControlNetModel.forward_body: shared prefix / the whole body once) -- what ControlAnimationPipeline tells them
+        # directly.  A caller with different halves gets the all-images path, as before.
+        same = bool(self.detect_identical_halves and do_classifier_free_guidance and not guess_mode and b == 2
+                    and torch.equal(control_model_input[0], control_model_input[1]))
+        down, mid = self.residuals_nhwc(x, t, controlnet_prompt_embeds, guess_mode, cfg_identical_halves=same)
 
         def to5(tn):  # [(b f),h,w,C] -> [b,C,f,h,w] view (no copy)
             bf, hh, ww, cc = tn.shape
