@@ -95,6 +95,9 @@ def parse():
                     help="multi-rank plumbing rehearsal WITHOUT the hot path (runs on a CPU box over gloo): rendezvous, "
                          "weight-arena broadcast, barriers, max-over-ranks timing, rank-0 JSON with `dry_run: true` and "
                          "`value: null`.  Never a measurement; used by tests/test_bench_launch.py")
+    ap.add_argument("--chains", type=int, default=2,
+                    help="after the headline (single GPU, outside `value`): N independent windows in flight on the one GPU (controlanimate_amd/chains.py), "
+                         "reported as `two_chains`; 1 skips it")
     ap.add_argument("--window-graph", action="store_true",
                     help="ControlAnimationPipeline.window_graph: a whole window as ONE captured hipGraph, one replay per window, no per-step events (A/B; "
                          "slower on ROCm 7.2 -- the launch cost of a graph grows with the square of its node count).  Default: one replay + three "
@@ -831,6 +834,55 @@ def measure(args, timer, rank, world, device, headline=True):
         roof_elapsed = time.perf_counter() - t1
         timer.enabled = False
         pipe.use_hip_graph, pipe.overlap_controlnet = not args.no_graph, not args.no_overlap
+    chains_out = None
+    if headline and world == 1 and args.chains > 1 and use_graph and not args.window_graph:
+        # Throughput mode, beside `value` and never part of it: `chains` independent windows in flight on this GPU -- each its own pipeline object
+        # (sampler, captured graph, static buffers) on its own stream and host thread over the same models.  Whole windows from a window start,
+        # 2 windows per chain timed after one priming window each.
+        from controlanimate_amd.chains import ChainSet
+        def job(seed):
+            return dict(video_length=f, input_frames=None, height=wl["height"], width=wl["width"], num_inference_steps=steps_per_window, strength=1.0,
+                        guidance_scale=guidance, generator=torch.Generator(device="cpu").manual_seed(seed), latents=lat0, prompt_embeds=pos,
+                        negative_prompt_embeds=neg, control_images=hints_dev, use_lcm=False, guess_mode=wl["guess_mode"], output_type="latent")
+        try:
+            cs = ChainSet(pipe, cn, chains=args.chains)
+            cs.map([job(10 + k) for k in range(args.chains)])          # priming: every chain captures its graph
+            torch.cuda.synchronize()
+            n_win = 2 * args.chains
+            tc0 = time.perf_counter()
+            res = cs.map([job(20 + k) for k in range(n_win)])          # (the first `chains` of them run one after the other: map()'s priming rule)
+            torch.cuda.synchronize()
+            tc = time.perf_counter() - tc0
+            # only the concurrent part is the mode's rate: time a second, all-concurrent batch by skipping map()'s serial prefix
+            import threading
+            def run_chain(k, out):
+                with torch.cuda.stream(cs.streams[k]):
+                    for w in range(2):
+                        kw = job(40 + 2 * k + w)
+                        kw["multicontrolnetresiduals_pipeline"] = cs.cns[k]
+                        out.append(cs.pipes[k](**kw))
+                cs.streams[k].synchronize()
+            outs = [[] for _ in range(args.chains)]
+            ths = [threading.Thread(target=run_chain, args=(k, outs[k])) for k in range(args.chains)]
+            torch.cuda.synchronize()
+            tc1 = time.perf_counter()
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+            torch.cuda.synchronize()
+            tcc = time.perf_counter() - tc1
+            ok = all(torch.isfinite(o.videos).all().item() for oo in outs for o in oo) and all(torch.isfinite(r.videos).all().item() for r in res)
+            steps_done = 2 * args.chains * steps_per_window
+            chains_out = {"chains": args.chains, "windows": 2 * args.chains, "ms_per_step_equivalent": round(1e3 * tcc / steps_done, 3),
+                          "frames_per_sec": round(2 * args.chains * f / tcc, 4), "finite": bool(ok),
+                          "replays_per_window": [int(p_.graph_replays) for p_ in cs.pipes],
+                          "mixed_batch_with_serial_priming_s": round(tc, 3),
+                          "note": "independent windows in flight on one GPU, one pipeline object per chain over shared models; a window's latency "
+                                  "is `chains` times the single-chain one; not part of `value`"}
+            del cs, res, outs
+        except Exception as exc:  # (never lose the headline to the side measurement)
+            chains_out = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     vae_ms = None
     if not args.no_vae and world == 1:  # single-GPU runs only: the other ranks of a scaling run must not wait for it
         vae_ms = time_vae(wl, device, dtype)
@@ -910,6 +962,7 @@ def measure(args, timer, rank, world, device, headline=True):
             "note": "SD1.5 AutoencoderKL on the same kernels, random weights; encode + decode of all frames of one window "
                     "(brackets the denoise steps; not part of `value`)"},
         "hip_graph": bool(use_graph),
+        "two_chains": chains_out,
         "controlnet_second_stream": bool(not args.no_overlap and nets),
     }
     if not args.no_roofline:

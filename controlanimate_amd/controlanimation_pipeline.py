@@ -62,6 +62,7 @@ class ControlAnimationPipeline:
         self.window_graph = False
         self.window_graph_fallback_reason = None
         self.window_replays = 0  # whole-window replays since construction (tests, bench)
+        self.graph_recapture_reason = None  # why the last call dropped a captured graph (None: it did not)
         # How far the host may run ahead of the device, in denoise steps.  An unpaced loop enqueues faster than the device
         # drains (a replay is ~3 us of host time per kernel against ~75 us of device time), fills the hardware queue and then
         # SPINS inside the runtime for the rest of every step: two cores per rank for nothing (round 4: 122 ms of CPU per
@@ -284,35 +285,52 @@ class ControlAnimationPipeline:
 
     # ---- what a captured hipGraph of the step reads besides its own pool ---------------------------------------------
     @staticmethod
-    def _model_cache_owners(unet, nets):
+    def _model_cache_owners(gs, unet, nets, cn):
         """Strong references to the buffers a captured step reads but the pipeline does not allocate: the models' per-window
         caches (prompt copy + text / IP K/V dict, hint embeddings) and their weight arenas, as they are at capture time."""
-        return {"unet": (unet._cache, unet._cache.get("ehs"), unet.arena),
-                "nets": [(n._cache, n._cache.get("ehs"), n._hint_emb, None if n._hint_key is None else n._hint_key[0], n.arena)
-                         for n in nets]}
+        def prompt_slot(m, src):
+            ent = m.cache_slot(src)
+            c = {} if ent is None else ent["cache"]
+            return c, c.get("ehs")
+        def hint_slot(n, k_):
+            ent = n.hint_slot(cn.prep_images[k_]) if cn is not None and cn.prep_images is not None else None
+            return (None, None) if ent is None else (ent["emb"], ent["src"])
+        return {"unet": (*prompt_slot(unet, gs["unet_prompt"]), unet.arena),
+                "nets": [(*prompt_slot(n, gs["cn_prompt"]), *hint_slot(n, k_), n.arena) for k_, n in enumerate(nets)]}
 
     @staticmethod
-    def _graph_owns_model_caches(gs, unet, nets, cn) -> bool:
-        """True while every such buffer is still the object the graph was captured on AND still keyed on the pipeline's
-        static prompt / control-image tensors (so that `refresh_window_caches` refreshes from the right source)."""
+    def _graph_lost_model_caches(gs, unet, nets, cn) -> Optional[str]:
+        """None while every such buffer is still the object the graph was captured on AND still keyed on the pipeline's static prompt /
+        control-image tensors (so that `refresh_window_caches` refreshes from the right source); else what changed.  The models keep one
+        cache slot per prompt / control-image tensor: the graph owns ITS slots as long as they are there -- another pipeline's slots
+        beside them do not matter."""
         own = gs.get("owned")
         if own is None:
-            return False
+            return "nothing recorded at capture time"
         c, ehs, arena = own["unet"]
-        key = unet._cache_key
-        if unet._cache is not c or c.get("ehs") is not ehs or unet.arena is not arena or key is None or key[0] is not gs["unet_prompt"]:
-            return False
+        ent = unet.cache_slot(gs["unet_prompt"])
+        if ent is None or ent["cache"] is not c or c.get("ehs") is not ehs:
+            return "the UNet's prompt cache slot was replaced or evicted"
+        if unet.arena is not arena:
+            return "the UNet's weight arena was re-packed"
         if len(own["nets"]) != len(nets):
-            return False
+            return "another number of ControlNets"
         for k_, (n, (c, ehs, hint, hint_src, arena)) in enumerate(zip(nets, own["nets"])):
-            key = n._cache_key
-            if n._cache is not c or c.get("ehs") is not ehs or n.arena is not arena or key is None or key[0] is not gs["cn_prompt"]:
-                return False
-            if n._hint_emb is not hint or n._hint_key is None or n._hint_key[0] is not hint_src:
-                return False
+            ent = n.cache_slot(gs["cn_prompt"])
+            if ent is None or ent["cache"] is not c or c.get("ehs") is not ehs:
+                return f"ControlNet {k_}'s prompt cache slot was replaced or evicted"
+            if n.arena is not arena:
+                return f"ControlNet {k_}'s weight arena was re-packed"
             if cn is None or cn.prep_images is None or cn.prep_images[k_] is not hint_src:
-                return False
-        return True
+                return f"ControlNet {k_}'s control-image tensor is another object"
+            hent = n.hint_slot(hint_src)
+            if hent is None or hent["emb"] is not hint:
+                return f"ControlNet {k_}'s hint-embedding slot was replaced or evicted"
+        return None
+
+    @classmethod
+    def _graph_owns_model_caches(cls, gs, unet, nets, cn) -> bool:
+        return cls._graph_lost_model_caches(gs, unet, nets, cn) is None
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -443,6 +461,7 @@ class ControlAnimationPipeline:
         use_graph = bool(self.use_hip_graph) and device.type == "cuda" and len(timesteps) > 1
         self.graph_replays = 0
         self.graph_fallback_reason = None
+        self.graph_recapture_reason = None
         gs = None
         if not use_graph and self._graph_state is not None:
             # a call that does not replay (use_hip_graph off, a one-step call): let go of the captured graph and of what it pins
@@ -451,6 +470,8 @@ class ControlAnimationPipeline:
         if use_graph:
             hh, ww = latents.shape[3], latents.shape[4]
             nets = list(getattr(cn, "controlnets", [])) if cn is not None else []
+            for m_ in (unet, *nets):  # (the signature names the weight arenas: pack them now if this is the models' first use)
+                m_._ensure_ready(device)
             sig = (id(unet), id(unet.arena), tuple(id(n.arena) for n in nets), id(cn), rep, f, hh, ww, cpad, str(unet.act_dtype),
                    tuple(unet_prompt.shape), tuple(cn_prompt.shape) if cn is not None else None, bool(cn_single), bool(guess_mode),
                    bool(use_lcm), w_embedding is not None, bool(getattr(self, "overlap_controlnet", True)), bool(getattr(self, "fuse_controlnet_adds", True)),
@@ -460,6 +481,8 @@ class ControlAnimationPipeline:
                    tuple(float(c) for c in cn.cond_scale) if cn is not None else None,
                    float(ipa_scale) if self.ip_adapter is not None else None)
             gs = self._graph_state
+            if gs is not None and gs["sig"] != sig:
+                self.graph_recapture_reason = "the call's signature changed at positions %s" % [i_ for i_, (a_, b_) in enumerate(zip(gs["sig"], sig)) if a_ != b_]
             if gs is None or gs["sig"] != sig:
                 gs = self._graph_state = {
                     "sig": sig, "graph": None, "eps": None, "owned": None, "wgraphs": {}, "lat_in": None,
@@ -477,17 +500,20 @@ class ControlAnimationPipeline:
                 gs["w"].copy_(w_embedding)
             unet_prompt, cn_prompt, w_embedding = gs["unet_prompt"], gs["cn_prompt"], gs["w"]
             captured = gs["graph"] is not None or bool(gs.get("wgraphs"))
-            if captured and not self._graph_owns_model_caches(gs, unet, nets, cn):
-                # an eager forward of the same models in between (another prompt tensor, a one-step call, a second pipeline
-                # sharing the UNet) replaced the caches the captured kernels read: their buffers may be freed or stale
-                logger.info("the models' per-window caches changed hands since the hipGraph was captured: capturing again")
+            lost = self._graph_lost_model_caches(gs, unet, nets, cn) if captured else None
+            if lost is not None:
+                self.graph_recapture_reason = lost
+            if lost is not None:
+                # the caches the captured kernels read were replaced (a re-prepared model, more pipelines on one model than it keeps
+                # cache slots for, a one-step call that let go of the graph): their buffers may be freed or stale
+                logger.info("capturing the hipGraph again: %s", lost)
                 gs["graph"] = gs["eps"] = gs["owned"] = None
                 gs["wgraphs"] = {}
                 captured = False
             if captured:  # a later window: the per-window caches (text / IP K/V, hint embeddings), in place
-                unet.refresh_window_caches()
-                for n_ in nets:
-                    n_.refresh_window_caches()
+                unet.refresh_window_caches(gs["unet_prompt"])
+                for k_, n_ in enumerate(nets):
+                    n_.refresh_window_caches(gs["cn_prompt"], cn.prep_images[k_])
 
         def model_eps(x, tt):
             down = mid = None
@@ -564,7 +590,7 @@ class ControlAnimationPipeline:
                     model_eps(gs["x"], gs["t"])
                     torch.cuda.synchronize()
                     g_ = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_):
+                    with torch.cuda.graph(g_, capture_error_mode="thread_local"):  # (another chain's thread may be launching meanwhile: chains.py)
                         lat_k, den_k = gs["lat_in"], None
                         for i, (t_k, scale_k, coef_k, clip_k) in enumerate(plan):
                             K.latents_to_nhwc(lat_k, cpad, rep, scale_k, unet.act_dtype, out=gs["x"])
@@ -576,7 +602,7 @@ class ControlAnimationPipeline:
                     if len(gs["wgraphs"]) >= 2:  # (a pipeline alternating more than two schedules: keep the two newest)
                         gs["wgraphs"].pop(next(iter(gs["wgraphs"])))
                     gs["wgraphs"][wkey] = ent
-                    gs["owned"] = self._model_cache_owners(unet, nets)
+                    gs["owned"] = self._model_cache_owners(gs, unet, nets, cn)
                     self.window_graph_fallback_reason = None
                 except Exception as exc:  # never silent, never fatal: this window runs on the per-step path
                     ent = None
@@ -605,10 +631,10 @@ class ControlAnimationPipeline:
                     try:
                         torch.cuda.synchronize()
                         g_ = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g_):
+                        with torch.cuda.graph(g_, capture_error_mode="thread_local"):  # (another chain's thread may be launching meanwhile: chains.py)
                             gs["eps"] = model_eps(gs["x"], gs["t"])
                         gs["graph"] = g_
-                        gs["owned"] = self._model_cache_owners(unet, nets)
+                        gs["owned"] = self._model_cache_owners(gs, unet, nets, cn)
                     except Exception as exc:  # capture is an optimisation only -- but never a silent one
                         use_graph = False
                         self._graph_state = None

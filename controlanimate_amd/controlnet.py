@@ -16,6 +16,7 @@ same NHWC kernels as the UNet.  Fusions:
 from __future__ import annotations
 
 import dataclasses
+from collections import OrderedDict
 
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -98,9 +99,8 @@ class ControlNetModel(HipModelMixin, nn.Module):
                                                  attn_num_head_channels=attention_head_dim[-1], **common)
         for m in list(self.controlnet_down_blocks) + [self.controlnet_mid_block]:
             nn.init.zeros_(m.weight)  # zero convs; checkpoints overwrite them
-        self._hint_key = None
-        self._hint_emb = None
-        self._hint_doubled = False
+        # hint embeddings, one slot per control-image tensor object (most recently used last; see HipModelMixin._slots)
+        self._hints: "OrderedDict[int, dict]" = OrderedDict()
 
     @classmethod
     def from_config(cls, config: dict, **kwargs):
@@ -109,20 +109,51 @@ class ControlNetModel(HipModelMixin, nn.Module):
         return cls(**merged)
 
     # ---------------------------------------------------------------------------------------
+    def hint_slot(self, controlnet_cond: Optional[torch.Tensor] = None) -> Optional[dict]:
+        """The slot of control-image tensor `controlnet_cond` ({"src", "version", "emb", "doubled"}) or the most recently used one."""
+        if controlnet_cond is None:
+            return next(reversed(self._hints.values())) if self._hints else None
+        ent = self._hints.get(id(controlnet_cond))
+        return ent if ent is not None and ent["src"] is controlnet_cond else None
+
+    @property
+    def _hint_emb(self):  # (most recently used slot: single-pipeline callers, tests)
+        ent = self.hint_slot()
+        return None if ent is None else ent["emb"]
+
+    @property
+    def _hint_key(self):
+        ent = self.hint_slot()
+        return None if ent is None else (ent["src"], ent["version"])
+
+    @property
+    def _hint_doubled(self) -> bool:
+        ent = self.hint_slot()
+        return bool(ent is not None and ent["doubled"])
+
     def hint_embedding(self, controlnet_cond: torch.Tensor, device) -> torch.Tensor:
         """controlnet_cond [B,3,H,W] in [0,1] -> NHWC embedding [B,H/8,W/8,C0]; cached while the same
         (unmodified) tensor object is passed, i.e. for all denoising steps of a window."""
-        key = self._hint_key
-        if key is not None and key[0] is controlnet_cond and self._hint_emb is not None:
-            if key[1] != controlnet_cond._version:  # the same tensor with new contents (the next window's frames): in place
-                self._hint_emb.copy_(self._embed_hints(controlnet_cond, device))
-                self._hint_key = (controlnet_cond, controlnet_cond._version)
-            return self._hint_emb
-        self._hint_emb = self._embed_hints(controlnet_cond, device)
-        self._hint_key = (controlnet_cond, controlnet_cond._version)
-        return self._hint_emb
+        return self._hint(controlnet_cond, device)["emb"]
 
-    def _embed_hints(self, controlnet_cond: torch.Tensor, device) -> torch.Tensor:
+    def _hint(self, controlnet_cond: torch.Tensor, device) -> dict:
+        ent = self.hint_slot(controlnet_cond)
+        if ent is not None:
+            self._hints.move_to_end(id(controlnet_cond))
+            if ent["version"] != controlnet_cond._version:  # the same tensor with new contents (the next window's frames): in place
+                emb, doubled = self._embed_hints(controlnet_cond, device)
+                ent["emb"].copy_(emb)
+                ent["doubled"], ent["version"] = doubled, controlnet_cond._version
+            return ent
+        emb, doubled = self._embed_hints(controlnet_cond, device)
+        ent = {"src": controlnet_cond, "version": controlnet_cond._version, "emb": emb, "doubled": doubled}
+        self._hints.pop(id(controlnet_cond), None)
+        self._hints[id(controlnet_cond)] = ent
+        while len(self._hints) > self.MAX_CACHE_SLOTS:
+            self._hints.popitem(last=False)
+        return ent
+
+    def _embed_hints(self, controlnet_cond: torch.Tensor, device):
         """The eight-convolution hint embedding (full-resolution 16- and 32-channel layers: the most expensive per-window
         work).  Hints that `prep_control_images` doubled for classifier-free guidance (`torch.cat([ctrl] * 2)`, reference
         :268-269) carry `_cfg_doubled`: the two halves are the same images, so one half is embedded and repeated -- the same
@@ -134,24 +165,25 @@ class ControlNetModel(HipModelMixin, nn.Module):
             half = cond.shape[0] // 2
             # the mark is a hint, the tensor is the truth: a caller may have edited one half in place since (regional control)
             doubled = bool(torch.equal(cond[:half], cond[half:]))
-        self._hint_doubled = doubled  # what forward_nhwc may rely on for THIS embedding (the shared prefix of the CFG halves)
+        # (`doubled` is what forward_body may rely on for THIS embedding: the shared prefix / the one-problem form of the CFG halves)
         if doubled:
             cond = cond[: cond.shape[0] // 2]
         emb = ce(K.ncfhw_to_nhwc(cond.to(device).unsqueeze(2), ce.conv_in.cin_pad, self.act_dtype))
-        return K.repeat_batch(emb) if doubled else emb
+        return (K.repeat_batch(emb) if doubled else emb), doubled
 
-    def refresh_window_caches(self) -> int:
-        """HipModelMixin.refresh_window_caches + the hint embedding of the current control images (in place)."""
-        n = super().refresh_window_caches()
-        if self._hint_key is not None and self._hint_emb is not None:
-            src = self._hint_key[0]
-            self._hint_emb.copy_(self._embed_hints(src, self._hint_emb.device))
-            self._hint_key = (src, src._version)
+    def refresh_window_caches(self, src: Optional[torch.Tensor] = None, hint_src: Optional[torch.Tensor] = None) -> int:
+        """HipModelMixin.refresh_window_caches + the hint embedding of the control images `hint_src` (default: the most recently used), in place."""
+        n = super().refresh_window_caches(src)
+        ent = self.hint_slot(hint_src)
+        if ent is not None:
+            emb, doubled = self._embed_hints(ent["src"], ent["emb"].device)
+            ent["emb"].copy_(emb)
+            ent["doubled"], ent["version"] = doubled, ent["src"]._version
             n += 1
         return n
 
     def prepare(self, device=None, dtype=None):
-        self._hint_key = self._hint_emb = None
+        self._hints.clear()
         return super().prepare(device, dtype)
 
     def residual_scales(self, conditioning_scale: float, guess_mode: bool) -> List[float]:
@@ -173,14 +205,15 @@ class ControlNetModel(HipModelMixin, nn.Module):
         temb = self._time_embedding(timestep, 1, device)
         ctx = ExecCtx(b=images, f=1, dtype=self.act_dtype, temb=temb, emb_groups=1, ehs=ehs, frames_per_kv=1, kv_mod=nb,
                       gn_frames_per_stat=1, cache=cache)
-        hint = self.hint_embedding(controlnet_cond, device)
+        hint_ent = self._hint(controlnet_cond, device)
+        hint = hint_ent["emb"]
         if hint.shape[0] != images:
             raise ValueError(f"controlnet_cond batch {hint.shape[0]} != sample batch {images}")
         # CFG-doubled input (the caller repeated one latent tensor, `cfg_identical_halves`) with CFG-doubled hints: the two
         # halves are identical up to the first cross-attention -- see UNet3DConditionModel.forward_nhwc
         first = self.down_blocks[0]
         from .context import dispatch
-        same_inputs = (cfg_identical_halves and images % 2 == 0 and bool(getattr(self, "_hint_doubled", False)) and
+        same_inputs = (cfg_identical_halves and images % 2 == 0 and bool(hint_ent["doubled"]) and
                        (not torch.is_tensor(timestep) or timestep.numel() == 1))
         # The reference tiles the ControlNet's prompt as torch.cat([embeds] * frame_count) (modules/controlresiduals_pipeline.py:292,
         # SURVEY App. C-1): image z of the (b f) batch reads embeds[z % nb].  With an even number of frames per CFG half

@@ -41,25 +41,28 @@ struct GnParams {
 
 // Thread mapping: tx = lane over 16-byte channel chunks, ty = lane over rows; TX = 2^txlog in {8,16,32,64} is the
 // choice with C/8 <= TX * slots (slots <= 5) that idles the fewest lanes, the smallest such TX on ties (more rows in
-// flight per block): C = 320/640/1280 -> TX = 8/16/32 with 5 slots, C = 128/256/512 (VAE) -> TX = 8/8/16 with
-// 2/4/4 slots (a 64-wide mapping idles 75% of the lanes at C = 128).  256/TX rows are in flight per block
+// flight per block): C = 320/640/1280 -> TX = 8/16/32 with 5 slots, C = 128/256/512 (VAE) -> TX = 8/16/32 with
+// 2/2/2 slots (a 64-wide mapping idles 75% of the lanes at C = 128).  256/TX rows are in flight per block
 // iteration, every thread issuing all its slot loads back to back.
 __host__ __device__ inline int gn_txlog(int c8) {
-  int best = 6, best_waste = 1 << 30;
+  // (ties in idle lanes, round 6: the mapping with TWO slots if there is one -- C = 128 / 256 / 512: TX = 8 / 16 / 32 -- the kernels' per-thread
+  //  arrays are instantiated per slot count, and two slots keep twice the waves per SIMD in flight that four do; else the smallest TX)
+  int best = 6, best_waste = 1 << 30, best_slots = 0;
   for (int l = 3; l <= 6; ++l) {
     const int tx = 1 << l, slots = (c8 + tx - 1) / tx;
     if (slots > 5) continue;
     const int waste = slots * tx - c8;
-    if (waste < best_waste) {
+    if (waste < best_waste || (waste == best_waste && best_slots != 2 && slots == 2)) {
       best_waste = waste;
       best = l;
+      best_slots = slots;
     }
   }
   return best;
 }
 
 // grid: (nchunks, n_stat_groups)
-template <int DT, int txlog>
+template <int DT, int txlog, int SLOTS = GN_MAX_SLOTS>
 __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
   __shared__ float ch_s[GN_MAX_C];
   __shared__ float ch_ss[GN_MAX_C];
@@ -73,9 +76,9 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
   if (r1 > p.rows_per_stat) r1 = p.rows_per_stat;
   const int64_t base_row = (int64_t)sg * p.rows_per_stat;
 
-  float s[GN_MAX_SLOTS][8], ss[GN_MAX_SLOTS][8];
+  float s[SLOTS][8], ss[SLOTS][8];
 #pragma unroll
-  for (int k = 0; k < GN_MAX_SLOTS; ++k)
+  for (int k = 0; k < SLOTS; ++k)
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[k][j] = ss[k][j] = 0.f;
 
@@ -88,11 +91,11 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
     if (piece * TY >= p.rows_per_stat) break;
     const bool ok[2] = {ra < p.rows_per_stat, rb < p.rows_per_stat};
     const int64_t rows2[2] = {base_row + ra, base_row + rb};
-    u32x4 raw[2][GN_MAX_SLOTS];
+    u32x4 raw[2][SLOTS];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      for (int k = 0; k < SLOTS; ++k) {
         const int c8 = tx + (k << txlog);
         if (c8 < C8 && ok[h]) {
           const int ch = c8 << 3;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      for (int k = 0; k < SLOTS; ++k) {
         if (tx + (k << txlog) < C8 && ok[h]) {
           float f[8];
           unpack8<DT>(raw[h][k], f);
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
     // instead of 8 channels -- 4x fewer shuffles, one barrier.  Fixed order everywhere (deterministic).
     __shared__ float part[4][GN_MAX_C / 8][4];
 #pragma unroll
-    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+    for (int k = 0; k < SLOTS; ++k) {
       const int c8 = tx + (k << txlog);
       if ((k << txlog) < C8) {
         const int g0 = (c8 << 3) / cpg;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
   // deterministic reduction: row lanes of one wave by xor-shuffles (fixed tree), then the four waves
   // one after the other through LDS
 #pragma unroll
-  for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+  for (int k = 0; k < SLOTS; ++k) {
     if ((k << txlog) < C8) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
   for (int w = 0; w < 4; ++w) {
     if (wave == w && lane < TX) {
 #pragma unroll
-      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      for (int k = 0; k < SLOTS; ++k) {
         const int c8 = tx + (k << txlog);
         if (c8 < C8) {
 #pragma unroll
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnParams p) {
   }
 }
 
-template <int DT, int txlog>
+template <int DT, int txlog, int SLOTS = GN_MAX_SLOTS>
 __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
   __shared__ double red[8][64][2];
   __shared__ float gm[64], gr[64];
@@ -256,9 +259,9 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
     __syncthreads();
   }
   // this thread's channels are the same for every row: keep their scale/shift in registers
-  float rs[GN_MAX_SLOTS][8], rh[GN_MAX_SLOTS][8];
+  float rs[SLOTS][8], rh[SLOTS][8];
 #pragma unroll
-  for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+  for (int k = 0; k < SLOTS; ++k) {
     const int c8 = tx + (k << txlog);
     if (c8 < C8) {
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + (c8 << 3)), g1 = *reinterpret_cast<const f32x4*>(p.gamma + (c8 << 3) + 4);
@@ -281,11 +284,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
     if (piece * TY >= p.rows_per_stat) break;
     const bool ok[2] = {ra < p.rows_per_stat, rb < p.rows_per_stat};
     const int64_t rows2[2] = {base_row + ra, base_row + rb};
-    u32x4 raw[2][GN_MAX_SLOTS];
+    u32x4 raw[2][SLOTS];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      for (int k = 0; k < SLOTS; ++k) {
         const int c8 = tx + (k << txlog);
         if (c8 < C8 && ok[h]) {
           const int ch = c8 << 3;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      for (int k = 0; k < SLOTS; ++k) {
         const int c8 = tx + (k << txlog);
         if (c8 < C8 && ok[h]) {
           float f[8];
@@ -904,23 +907,34 @@ extern "C" int64_t ca_groupnorm_partials_floats(int32_t images, int32_t hw, int3
   return nstat * gn_chunks_host((int64_t)frames_per_stat * hw) * groups * 2;
 }
 
+// The kernels keep per-thread arrays of SLOTS channel chunks (scale / shift, running sums, two rows of raw data): instantiated for the slot
+// counts the mapping produces -- 2 (C = 128: the VAE's 512x512 level), 4 (256 / 512 / 960 / 1920) and 5 (320 / 640 / 1280 / 2560) -- so that a
+// narrow tensor does not carry the registers of five slots (round 6: 140 -> ~70 VGPRs at C = 128, twice the waves per SIMD in flight).
+template <int DT, int L>
+void launch_gn_l(bool apply, int slots, const GnParams& p, dim3 grid, hipStream_t st) {
+  if (slots <= 2) {
+    if (apply) hipLaunchKernelGGL((k_gn_apply<DT, L, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gn_stats<DT, L, 2>), grid, dim3(256), 0, st, p);
+  } else if (slots <= 4) {
+    if (apply) hipLaunchKernelGGL((k_gn_apply<DT, L, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gn_stats<DT, L, 4>), grid, dim3(256), 0, st, p);
+  } else {
+    if (apply) hipLaunchKernelGGL((k_gn_apply<DT, L, 5>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gn_stats<DT, L, 5>), grid, dim3(256), 0, st, p);
+  }
+}
+
 template <int DT>
 void launch_gn(bool apply, const GnParams& p, dim3 grid, hipStream_t st) {
-  const int txlog = gn_txlog((p.c1 + p.c2) >> 3);
-#define CA_GN_CASE(L)                                                                         \
-  case L:                                                                                     \
-    if (apply) hipLaunchKernelGGL((k_gn_apply<DT, L>), grid, dim3(256), 0, st, p);            \
-    else hipLaunchKernelGGL((k_gn_stats<DT, L>), grid, dim3(256), 0, st, p);                  \
-    break;
+  const int c8 = (p.c1 + p.c2) >> 3;
+  const int txlog = gn_txlog(c8);
+  const int slots = (c8 + (1 << txlog) - 1) >> txlog;
   switch (txlog) {
-    CA_GN_CASE(3)
-    CA_GN_CASE(4)
-    CA_GN_CASE(5)
-    default:
-      if (apply) hipLaunchKernelGGL((k_gn_apply<DT, 6>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((k_gn_stats<DT, 6>), grid, dim3(256), 0, st, p);
+    case 3: launch_gn_l<DT, 3>(apply, slots, p, grid, st); break;
+    case 4: launch_gn_l<DT, 4>(apply, slots, p, grid, st); break;
+    case 5: launch_gn_l<DT, 5>(apply, slots, p, grid, st); break;
+    default: launch_gn_l<DT, 6>(apply, slots, p, grid, st);
   }
-#undef CA_GN_CASE
 }
 
 extern "C" int ca_groupnorm_stats(const ca_groupnorm_args* a, void* stream) {

@@ -15,6 +15,8 @@ same forward signature and output type.  What is different is everything underne
 """
 from __future__ import annotations
 
+from collections import OrderedDict
+
 import dataclasses
 import json
 import os
@@ -76,8 +78,10 @@ class HipModelMixin:
         # (prepare(dtype=torch.bfloat16)) for range safety but measures 1.8e-2 through the ~150 residual adds.
         self.act_dtype = torch.float16
         self._temb_w = self._temb_b = None
-        self._cache: dict = {}
-        self._cache_key = None
+        # per-window caches (prompt copy, text / IP K/V ...), one SLOT per prompt tensor object the model is called with (most recently used
+        # last, at most MAX_CACHE_SLOTS): two pipelines that share this model -- two windows in flight, a facade alternating two configurations
+        # -- each keep the buffers their captured hipGraphs read (round 6; one slot until round 5: every other prompt tensor evicted it)
+        self._slots: "OrderedDict[int, dict]" = OrderedDict()
 
     # ---- weights ---------------------------------------------------------------------------
     def all_resnets(self):
@@ -106,23 +110,43 @@ class HipModelMixin:
         self._temb_b = pack_concat_bias(arena, [r.time_emb_proj for r in resnets])
         arena.finalize(device)
         self.arena = arena
-        self._cache, self._cache_key = {}, None
+        self._slots.clear()
         return self
 
-    def refresh_window_caches(self) -> int:
+    MAX_CACHE_SLOTS = 4
+
+    def cache_slot(self, src: Optional[torch.Tensor] = None) -> Optional[dict]:
+        """The cache slot of prompt tensor `src` ({"src", "version", "cache"}), or the most recently used one; None if there is none."""
+        if src is None:
+            return next(reversed(self._slots.values())) if self._slots else None
+        ent = self._slots.get(id(src))
+        return ent if ent is not None and ent["src"] is src else None
+
+    @property
+    def _cache(self) -> dict:  # (the most recently used slot's dictionary: what single-pipeline callers and tests look at)
+        ent = self.cache_slot()
+        return ent["cache"] if ent is not None else {}
+
+    @property
+    def _cache_key(self):
+        ent = self.cache_slot()
+        return (ent["src"], ent["version"]) if ent is not None else None
+
+    def refresh_window_caches(self, src: Optional[torch.Tensor] = None) -> int:
         """Recomputes, IN PLACE, everything this model caches across the denoising steps of a window from the prompt:
         the activation-dtype copy of the prompt embeddings, the text K/V of every cross-attention site (and the IP-Adapter
         K/V).  In place = every cached buffer keeps its address, so a captured hipGraph that reads them stays valid: the
         pipeline keeps ONE prompt tensor per signature, copies each window's embeddings into it and calls this before it
         replays (ControlAnimationPipeline.__call__); a forward that is handed the same tensor object with new contents
-        does the same on its own (`_prompt`).  Returns the number of GEMMs issued."""
-        cache, key = self._cache, self._cache_key
-        ehs = cache.get("ehs")
-        if ehs is None or key is None:
+        does the same on its own (`_prompt`).  `src`: the prompt tensor whose slot is refreshed (default: the most recently used one).
+        Returns the number of GEMMs issued."""
+        ent = self.cache_slot(src)
+        if ent is None or ent["cache"].get("ehs") is None:
             return 0
-        src = key[0]
+        cache, src = ent["cache"], ent["src"]
+        ehs = cache["ehs"]
         ehs.copy_(src.to(device=ehs.device, dtype=ehs.dtype))
-        self._cache_key = (src, src._version)
+        ent["version"] = src._version
         nb, L, cd = ehs.shape
         n = 0
         for m in self.modules():
@@ -176,6 +200,9 @@ class HipModelMixin:
         return next(self.parameters()).device
 
     def _ensure_ready(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:  # ("cuda" names the current device: it must not look different from "cuda:0")
+            device = torch.device("cuda", torch.cuda.current_device())
         if self.arena is None or self.arena.buffer is None or self.arena.buffer.device != device:
             self.prepare(device)
 
@@ -241,16 +268,20 @@ class HipModelMixin:
     def _prompt(self, encoder_hidden_states: torch.Tensor, device) -> Tuple[torch.Tensor, dict]:
         """Prompt embeddings in the activation dtype + the K/V cache that belongs to them. The cache
         survives across calls only while the caller passes the very same (unmodified) tensor."""
-        key = self._cache_key
-        if key is not None and key[0] is encoder_hidden_states and "ehs" in self._cache and \
-                tuple(self._cache["ehs"].shape) == tuple(encoder_hidden_states.shape):
-            if key[1] != encoder_hidden_states._version:  # the same tensor with new contents: refresh in place (addresses stay)
-                self.refresh_window_caches()
-            return self._cache["ehs"], self._cache
-        ehs = encoder_hidden_states.to(device=device, dtype=self.act_dtype).contiguous()
-        self._cache = {"ehs": ehs}
-        self._cache_key = (encoder_hidden_states, encoder_hidden_states._version)
-        return ehs, self._cache
+        src = encoder_hidden_states
+        ent = self.cache_slot(src)
+        if ent is not None and "ehs" in ent["cache"] and tuple(ent["cache"]["ehs"].shape) == tuple(src.shape):
+            self._slots.move_to_end(id(src))
+            if ent["version"] != src._version:  # the same tensor with new contents: refresh in place (addresses stay)
+                self.refresh_window_caches(src)
+            return ent["cache"]["ehs"], ent["cache"]
+        ehs = src.to(device=device, dtype=self.act_dtype).contiguous()
+        ent = {"src": src, "version": src._version, "cache": {"ehs": ehs}}
+        self._slots.pop(id(src), None)
+        self._slots[id(src)] = ent
+        while len(self._slots) > self.MAX_CACHE_SLOTS:
+            self._slots.popitem(last=False)  # (least recently used; a graph captured on it notices through _graph_owns_model_caches)
+        return ehs, ent["cache"]
 
 
 class UNet3DConditionModel(HipModelMixin, nn.Module):
