@@ -846,38 +846,18 @@ def measure(args, timer, rank, world, device, headline=True):
                         negative_prompt_embeds=neg, control_images=hints_dev, use_lcm=False, guess_mode=wl["guess_mode"], output_type="latent")
         try:
             cs = ChainSet(pipe, cn, chains=args.chains)
-            cs.map([job(10 + k) for k in range(args.chains)])          # priming: every chain captures its graph
-            torch.cuda.synchronize()
-            n_win = 2 * args.chains
-            tc0 = time.perf_counter()
-            res = cs.map([job(20 + k) for k in range(n_win)])          # (the first `chains` of them run one after the other: map()'s priming rule)
-            torch.cuda.synchronize()
-            tc = time.perf_counter() - tc0
-            # only the concurrent part is the mode's rate: time a second, all-concurrent batch by skipping map()'s serial prefix
-            import threading
-            def run_chain(k, out):
-                with torch.cuda.stream(cs.streams[k]):
-                    for w in range(2):
-                        kw = job(40 + 2 * k + w)
-                        kw["multicontrolnetresiduals_pipeline"] = cs.cns[k]
-                        out.append(cs.pipes[k](**kw))
-                cs.streams[k].synchronize()
-            outs = [[] for _ in range(args.chains)]
-            ths = [threading.Thread(target=run_chain, args=(k, outs[k])) for k in range(args.chains)]
+            cs.map([job(10 + k) for k in range(args.chains)], timeout_s=300)          # priming: every chain captures its graph, one at a time
             torch.cuda.synchronize()
             tc1 = time.perf_counter()
-            for t_ in ths:
-                t_.start()
-            for t_ in ths:
-                t_.join()
+            res = cs.map([job(40 + k) for k in range(2 * args.chains)], prime=False, timeout_s=300)  # two windows per chain, all concurrent
             torch.cuda.synchronize()
             tcc = time.perf_counter() - tc1
-            ok = all(torch.isfinite(o.videos).all().item() for oo in outs for o in oo) and all(torch.isfinite(r.videos).all().item() for r in res)
+            outs = [res]
+            ok = all(torch.isfinite(o.videos).all().item() for oo in outs for o in oo)
             steps_done = 2 * args.chains * steps_per_window
             chains_out = {"chains": args.chains, "windows": 2 * args.chains, "ms_per_step_equivalent": round(1e3 * tcc / steps_done, 3),
                           "frames_per_sec": round(2 * args.chains * f / tcc, 4), "finite": bool(ok),
                           "replays_per_window": [int(p_.graph_replays) for p_ in cs.pipes],
-                          "mixed_batch_with_serial_priming_s": round(tc, 3),
                           "note": "independent windows in flight on one GPU, one pipeline object per chain over shared models; a window's latency "
                                   "is `chains` times the single-chain one; not part of `value`"}
             del cs, res, outs

@@ -58,9 +58,10 @@ class ChainSet:
         self.cns = [cn] + [clone_residuals_pipeline(cn) for _ in range(chains - 1)]
         self.streams = [torch.cuda.Stream(device=pipe.device) for _ in range(chains)]
 
-    def map(self, jobs: Sequence[Dict[str, Any]]) -> List[Any]:
-        """Runs `pipe(**job)` for every job -- chain k takes jobs k, k + chains, ... -- and returns the results in job order.  The first job
-        of every chain runs alone (its eager step and the hipGraph capture), the rest concurrently."""
+    def map(self, jobs: Sequence[Dict[str, Any]], prime: bool = True, timeout_s: Optional[float] = None) -> List[Any]:
+        """Runs `pipe(**job)` for every job -- chain k takes jobs k, k + chains, ... -- and returns the results in job order.  prime: the
+        first job of every chain runs alone (its eager step and the hipGraph capture; pass False once every chain has captured), the rest
+        concurrently.  timeout_s: give up (TimeoutError) when the concurrent part takes longer -- the worker threads are daemons."""
         n = len(self.pipes)
         results: List[Any] = [None] * len(jobs)
         errors: List[Optional[BaseException]] = [None] * n
@@ -79,15 +80,22 @@ class ChainSet:
             except BaseException as exc:  # noqa: BLE001 -- re-raised in the caller's thread
                 errors[k] = exc
 
-        for k in range(min(n, len(jobs))):  # priming: one chain at a time
-            run(k, [k])
-            if errors[k] is not None:
-                raise errors[k]
-        threads = [threading.Thread(target=run, args=(k, list(range(k + n, len(jobs), n))), name=f"chain{k}") for k in range(n)]
+        first = 0
+        if prime:
+            for k in range(min(n, len(jobs))):  # priming: one chain at a time
+                run(k, [k])
+                if errors[k] is not None:
+                    raise errors[k]
+            first = n
+        threads = [threading.Thread(target=run, args=(k, list(range(k + first, len(jobs), n))), name=f"chain{k}", daemon=True) for k in range(n)]
         for t in threads:
             t.start()
+        import time
+        deadline = None if timeout_s is None else time.monotonic() + float(timeout_s)
         for t in threads:
-            t.join()
+            t.join(None if deadline is None else max(0.0, deadline - time.monotonic()))
+            if t.is_alive():
+                raise TimeoutError(f"chain thread {t.name} did not finish within {timeout_s} s")
         for e in errors:
             if e is not None:
                 raise e

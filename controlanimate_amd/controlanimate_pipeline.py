@@ -144,6 +144,21 @@ class ControlAnimatePipeline:
             self.n_prompt = self.pipeline.maybe_convert_prompt(self.n_prompt, self.pipeline.tokenizer)
         self._embeds = components.get("prompt_embeds"), components.get("negative_prompt_embeds")
 
+    def twin(self) -> "ControlAnimatePipeline":
+        """A second facade over the SAME models for a second window in flight on this GPU (chains.py): its own denoising pipeline
+        (sampler, captured hipGraph, static buffers), its own residuals pipeline (control-image tensors, side streams) and generator;
+        the models, the prompt encoder and the encoded prompts are shared.  Nothing is loaded or packed again."""
+        from .chains import clone_pipeline, clone_residuals_pipeline
+        if not self._prepared:
+            self._prepare_models()
+        other = object.__new__(ControlAnimatePipeline)
+        other.__dict__.update(self.__dict__)
+        other.pipeline = clone_pipeline(self.pipeline)
+        other.multicontrolnetresiduals_pipeline = clone_residuals_pipeline(self.multicontrolnetresiduals_pipeline)
+        self._prompt_embeds() if self.encode_prompt is not None or self._embeds[0] is not None else None
+        other._embeds = self._embeds
+        return other
+
     def _prepare_models(self):
         """Packs the weights into their device arenas (needs the HIP device; there is no CPU path)."""
         models = [self.pipeline.unet] + (list(self.multicontrolnetresiduals_pipeline.controlnets) if self.multicontrolnetresiduals_pipeline else [])

@@ -335,10 +335,48 @@ def blend_windows(windows: Sequence[Sequence], overlap_length: int,
     return out
 
 
+def _run_windows_on_chains(pipe, plan, frames, cfg_of, ip_kw, rank, world, chains, device):
+    """This rank's windows (r, r + W, ...) on `chains` facades over one set of models, one host thread and HIP stream each; the first
+    window of every chain runs alone (eager step + hipGraph capture).  -> [(window index, uint8 frames [n, H, W, 3])]."""
+    import threading
+    import torch
+    from . import window_shard as WS
+    mine = WS.windows_for_rank(len(plan), rank, world)
+    facades = [pipe] + [pipe.twin() for _ in range(chains - 1)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(chains)]
+    results, errors = {}, [None] * chains
+
+    def run(c, idxs):
+        try:
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(streams[c]):
+                for k in idxs:
+                    s, e = plan[k]
+                    out = facades[c].animate(frames[s:e], None, cfg_of(k), **ip_kw)
+                    results[k] = torch.from_numpy(np.stack([_to_np(f) for f in out]))
+            streams[c].synchronize()
+        except BaseException as exc:  # noqa: BLE001 -- re-raised in the caller's thread
+            errors[c] = exc
+
+    for c in range(min(chains, len(mine))):
+        run(c, [mine[c]])
+        if errors[c] is not None:
+            raise errors[c]
+    threads = [threading.Thread(target=run, args=(c, mine[c + chains::chains]), name=f"chain{c}", daemon=True) for c in range(chains)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    return [(k, results[k]) for k in mine]
+
+
 def run_video_sharded(config, frames: Sequence, components: Optional[dict] = None,
                       match_colors_fn: Optional[Callable[[Sequence, object], List]] = match_colors, device=None,
                       image_prompt_embeds=None, uncond_image_prompt_embeds=None, ip_reference_image=None,
-                      single_rank_group: bool = False):
+                      single_rank_group: bool = False, chains_per_gpu: int = 1):
     """The window loop of scripts/vid2vid.py:168-268 over the GPUs of one node: one process per GPU (torchrun or any launcher
     that sets RANK / LOCAL_RANK / WORLD_SIZE), every rank calls this with the same `config` and the same input `frames`.
 
@@ -372,7 +410,11 @@ def run_video_sharded(config, frames: Sequence, components: Optional[dict] = Non
     from the SAME generator as the VAE's latent sampling -- diffusers' ancestral / LCM samplers -- sees a different generator
     state in the two modes, because the sequential loop also encodes the previous window's frames: statistically the same
     video, not the same bits.  Deterministic samplers and the native LCM sampler, whose noise comes from the global RNG that
-    `animate` re-seeds per window, agree bit for bit.)"""
+    `animate` re-seeds per window, agree bit for bit.)
+
+    chains_per_gpu > 1 (round 6): every rank keeps that many of ITS windows in flight on its GPU -- `ControlAnimatePipeline.twin()` facades
+    over the same models, one host thread and HIP stream each (chains.py): the same frames, bit for bit, a few per cent more of them per
+    second.  Not with the native LCM sampler (`use_lcm`), whose step noise comes from torch's global generator."""
     import torch
     from . import window_shard as WS
     from .controlanimate_pipeline import ControlAnimatePipeline, _get
@@ -447,7 +489,14 @@ def run_video_sharded(config, frames: Sequence, components: Optional[dict] = Non
         out = pipe.animate(frames[s:e], None, cfg_of(k), **ip_kw)
         return torch.from_numpy(np.stack([_to_np(f) for f in out]))  # [n, H, W, 3] uint8
 
-    windows = WS.run_sharded(len(plan), run_window, rank, world)
+    if int(chains_per_gpu) > 1:
+        if bool(_get(config, "use_lcm", 0)):
+            raise ValueError("chains_per_gpu > 1 needs a sampler that draws from its own generator: the native LCM sampler (use_lcm) reads "
+                             "torch's global generator, which two windows in flight would interleave")
+        windows = WS.gather_window_results(_run_windows_on_chains(pipe, plan, frames, cfg_of, ip_kw, rank, world, int(chains_per_gpu), device),
+                                           len(plan))
+    else:
+        windows = WS.run_sharded(len(plan), run_window, rank, world)
     run_video_sharded.last_broadcast_bytes = moved
     if rank != 0 or windows is None:
         return None

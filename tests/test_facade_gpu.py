@@ -126,6 +126,33 @@ def test_sharded_video_equals_sequential(tmp_path):
     assert np.array_equal(sharded, seq), f"{int((sharded != seq).sum())} bytes differ"
 
 
+def test_sharded_video_with_two_windows_in_flight_equals_sequential():
+    """run_video_sharded(chains_per_gpu=2): this rank's windows on two facades (`ControlAnimatePipeline.twin()`: one set of models, two
+    denoising / residuals pipelines, two host threads and HIP streams -- VAE encode, text encoder, ControlNet + UNet3D loop, VAE decode of
+    two windows in flight) == the sequential loop of scripts/vid2vid.py:168-268 (`run_windows`), byte for byte.  36 frames = 8 windows."""
+    from controlanimate_amd import vid2vid
+    from controlanimate_amd.controlanimate_pipeline import ControlAnimatePipeline
+    cfg = dict(use_lcm=0, controlnets=["lllyasviel/control_v11p_sd15_canny"], cond_scale=[0.8], scheduler="DDIMScheduler",
+               prompt="a red fox running", n_prompt="blurry", seed=7, width=64, height=64, steps=3, strength=1.0, overlap_strength=1.0,
+               guidance_scale=1.3, frame_count=8, overlap_length=4, overlaps=0, epoch=0, guess_mode=0, use_img2img=True, loop_back_frames=False)
+    rng = np.random.default_rng(321)
+    frames = [Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)) for _ in range(36)]
+    comps = _components()
+    pipe = ControlAnimatePipeline(cfg, comps, device=DEV)
+    wc = vid2vid.WindowConfig(frame_count=8, overlap_length=4, strength=1.0, overlap_strength=1.0, loop_back_frames=False)
+
+    def animate(batch, last, c):
+        return pipe.animate(batch, last, dict(cfg, frame_count=c.frame_count, strength=c.strength, overlaps=c.overlaps, epoch=c.epoch))
+
+    seq = np.stack([np.asarray(f) for win in vid2vid.run_windows(frames, animate, wc) for f in win])
+    assert seq.shape == (36, 64, 64, 3)
+    two = vid2vid.run_video_sharded(cfg, frames, components=comps, device=DEV, chains_per_gpu=2)
+    two = np.stack([np.asarray(f) for f in two])
+    assert two.shape == seq.shape and np.array_equal(two, seq), f"{int((two != seq).sum())} bytes differ"
+    with pytest.raises(ValueError, match="use_lcm"):
+        vid2vid.run_video_sharded(dict(cfg, use_lcm=1), frames, components=comps, device=DEV, chains_per_gpu=2)
+
+
 # ---- BASELINE config 4's shape of problem: IP-Adapter + window sharding (fixed image prompt) ----------------------------------
 def _img_enc(pil):
     """Stand-in for the CLIP vision tower (PIL -> [1, 1024] image embedding), deterministic in the pixels."""
