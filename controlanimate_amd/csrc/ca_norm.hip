@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p) {
 // -- read once, statistics, normalise, write.  Needs cpg % 8 == 0 (a 16-byte chunk inside one norm group: cpg = 40 / 80)
 // and rows * cpg / 8 <= 256 * GNS_MAX chunks.  Deterministic (fixed shuffle tree, ordered LDS pass, fp64 finish).
 constexpr int GNS_MAX = 12;
-template <int DT>
+template <int DT, int NCH = GNS_MAX>  // NCH = chunks a thread holds: instantiated for 2 / 5 / 12 (round 6: a [32, 16, 16, 1280] launch needs 5, not the registers of 12)
 __global__ __launch_bounds__(256) void k_gn_small(GnParams p) {
   __shared__ double red[4][2];
   __shared__ float mr[2];
@@ -330,10 +330,10 @@ __global__ __launch_bounds__(256) void k_gn_small(GnParams p) {
   const int total = (int)p.rows_per_stat * q;
   const int64_t base_row = (int64_t)sg * p.rows_per_stat;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  u32x4 raw[GNS_MAX];
+  u32x4 raw[NCH];
   float s = 0.f, ss = 0.f;
 #pragma unroll
-  for (int k = 0; k < GNS_MAX; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int id = threadIdx.x + k * 256;
     if (id < total) {
       const int row = id / q, ch = g * cpg + (id - row * q) * 8;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_gn_small(GnParams p) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < GNS_MAX; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     if (threadIdx.x + k * 256 < total) {
       float f[8];
       unpack8<DT>(raw[k], f);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k_gn_small(GnParams p) {
   __syncthreads();
   const float mean = mr[0], rstd = mr[1];
 #pragma unroll
-  for (int k = 0; k < GNS_MAX; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int id = threadIdx.x + k * 256;
     if (id < total) {
       const int row = id / q, ch = g * cpg + (id - row * q) * 8;
@@ -409,21 +409,22 @@ __device__ __forceinline__ unsigned gnw_pk_sub(unsigned a, unsigned b) {
   return r;
 }
 constexpr int GNW_MAX_ROWS = 256, GNW_MAX_CPG = 80;
+template <int NCH, int CPG_MAX>  // chunks a thread holds (2 / 5 / 12) and the widest norm group the LDS slab is sized for (40: 20 KB, 80: 40 KB)
 __global__ __launch_bounds__(256) void k_gn_small_wino(GnParams p) {
   constexpr int DT = CA_F16;
   __shared__ double red[4][2];
   __shared__ float mr[2];
-  __shared__ __attribute__((aligned(16))) u16 slab[GNW_MAX_ROWS * GNW_MAX_CPG];
+  __shared__ __attribute__((aligned(16))) u16 slab[GNW_MAX_ROWS * CPG_MAX];
   const int C = p.c1 + p.c2;
   const int cpg = C / p.groups, q = cpg >> 3;
   const int g = blockIdx.x, sg = blockIdx.y;  // (frames_per_stat == 1: statistics group = image)
   const int total = (int)p.rows_per_stat * q;
   const int64_t base_row = (int64_t)sg * p.rows_per_stat;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  u32x4 raw[GNS_MAX];
+  u32x4 raw[NCH];
   float s = 0.f, ss = 0.f;
 #pragma unroll
-  for (int k = 0; k < GNS_MAX; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int id = threadIdx.x + k * 256;
     if (id < total) {
       const int row = id / q, ch = g * cpg + (id - row * q) * 8;
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void k_gn_small_wino(GnParams p) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < GNS_MAX; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     if (threadIdx.x + k * 256 < total) {
       float f[8];
       unpack8<DT>(raw[k], f);
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(256) void k_gn_small_wino(GnParams p) {
   __syncthreads();
   const float mean = mr[0], rstd = mr[1];
 #pragma unroll
-  for (int k = 0; k < GNS_MAX; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int id = threadIdx.x + k * 256;
     if (id < total) {
       const int row = id / q, cq = id - row * q, ch = g * cpg + cq * 8;
@@ -995,7 +996,19 @@ extern "C" int ca_groupnorm(const ca_groupnorm_args* a, void* stream) {
     p.act = a->act;
     p.wino_v = (u16*)a->wino_v;
     p.wino_h = a->wino_h, p.wino_w = a->wino_w;
-    hipLaunchKernelGGL(k_gn_small_wino, dim3(a->groups, a->images), dim3(256), 0, (hipStream_t)stream, p);
+    {
+      const int cpg_w = (a->c1 + a->c2) / a->groups;
+      const int64_t per_thread = ((int64_t)a->hw * (cpg_w >> 3) + 255) / 256;
+      const dim3 grid_w(a->groups, a->images);
+      hipStream_t st_w = (hipStream_t)stream;
+#define CA_GNW_CASE(N)                                                                                  \
+  if (cpg_w <= 40) hipLaunchKernelGGL((k_gn_small_wino<N, 40>), grid_w, dim3(256), 0, st_w, p);         \
+  else hipLaunchKernelGGL((k_gn_small_wino<N, GNW_MAX_CPG>), grid_w, dim3(256), 0, st_w, p);
+      if (per_thread <= 2) { CA_GNW_CASE(2) }
+      else if (per_thread <= 5) { CA_GNW_CASE(5) }
+      else { CA_GNW_CASE(GNS_MAX) }
+#undef CA_GNW_CASE
+    }
     CA_CHECK_LAUNCH("ca_groupnorm(wino)");
     return CA_OK;
   }
@@ -1004,8 +1017,14 @@ extern "C" int ca_groupnorm(const ca_groupnorm_args* a, void* stream) {
   CA_REQUIRE(a->y && a->gamma && a->beta, "ca_groupnorm: null operand");
   if (gn_small_ok(p)) {
     const dim3 grid(p.groups, a->images / a->frames_per_stat);
-    if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_gn_small<CA_BF16>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((k_gn_small<CA_F16>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    const int64_t per_thread = (p.rows_per_stat * ((p.c1 + p.c2) / p.groups >> 3) + 255) / 256;
+#define CA_GNS_CASE(N)                                                                                                     \
+  if (a->dtype == CA_BF16) hipLaunchKernelGGL((k_gn_small<CA_BF16, N>), grid, dim3(256), 0, (hipStream_t)stream, p);       \
+  else hipLaunchKernelGGL((k_gn_small<CA_F16, N>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (per_thread <= 2) { CA_GNS_CASE(2) }
+    else if (per_thread <= 5) { CA_GNS_CASE(5) }
+    else { CA_GNS_CASE(GNS_MAX) }
+#undef CA_GNS_CASE
     CA_CHECK_LAUNCH("ca_groupnorm");
     return CA_OK;
   }

@@ -9,9 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}_prof
 mkdir -p "$OUT" profiles
-PMCARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-roofline --no-overlap --no-graph --no-other-configs"
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -o run -- python3 bench.py --no-cpu-baseline --no-vae --no-other-configs --shapes > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace1s" -o run -- python3 bench.py --no-cpu-baseline --no-vae --no-roofline --no-overlap --no-graph --no-other-configs > "$OUT/trace1s_bench.json" 2> "$OUT/trace1s.err"
+PMCARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-roofline --no-overlap --no-graph --no-other-configs --chains 1"
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -o run -- python3 bench.py --no-cpu-baseline --no-vae --no-other-configs --chains 1 --shapes > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace1s" -o run -- python3 bench.py --no-cpu-baseline --no-vae --no-roofline --no-overlap --no-graph --no-other-configs --chains 1 > "$OUT/trace1s_bench.json" 2> "$OUT/trace1s.err"
 rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/fetch" -o run -- python3 bench.py $PMCARGS > /dev/null 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/write" -o run -- python3 bench.py $PMCARGS > /dev/null 2> "$OUT/write.err"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -f csv -d "$OUT/sq" -o run -- python3 bench.py $PMCARGS > /dev/null 2> "$OUT/sq.err"
