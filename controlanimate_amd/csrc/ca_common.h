@@ -145,6 +145,7 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 // polynomial, same operation order per element: bit-identical to gelu_erf_f.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
+#ifndef CA_GELU_SCALAR  // v_pk_fma_f32 / v_pk_mul_f32: 9 + 3 packed instructions per pair (the product form)
   const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
   const f32x2 u = xc * xc;
   f32x2 p = {-1.726317873e-12f, -1.726317873e-12f};
@@ -158,6 +159,14 @@ __device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
   p = __builtin_elementwise_fma(p, u, (f32x2){-6.642068177e-02f, -6.642068177e-02f});
   p = __builtin_elementwise_fma(p, u, (f32x2){3.989246786e-01f, 3.989246786e-01f});
   return __builtin_elementwise_fma(x, xc * p, (f32x2){0.5f, 0.5f} * x);
+#else
+  // -DCA_GELU_SCALAR (A/B builds): two scalar evaluations.  Round 6 measured a packed fp32 instruction at 2.8 v_fma_f32 issue times at 2-4 waves
+  // per SIMD (tools/probe_valu_rates.hip), i.e. 1.4 per element -- but the step does not notice (packed / scalar, same box, ms per step:
+  // 49.62 / 49.79, 49.48 / 49.53) and the scalar form spills in the epilogues of k_gemm_ps: the packed form stays.  Bit-identical either way.
+  float a = x[0], b = x[1];
+  asm volatile("" : "+v"(a), "+v"(b));
+  return (f32x2){gelu_erf_f(a), gelu_erf_f(b)};
+#endif
 }
 
 // epilogue activation selected at run time (wave-uniform)
