@@ -50,6 +50,31 @@ def clone_residuals_pipeline(cn: Optional[MultiControlNetResidualsPipeline]) -> 
     return twin
 
 
+class one_host_thread:
+    """torch's intra-op thread count is process-wide: with several chains in flight it is set to 1 ONCE around all of them (and restored), and
+    the pipelines' own per-call switch (`single_host_thread`: read, set 1, restore) is off meanwhile -- two threads restoring each other's
+    readings would leave the process at one thread."""
+
+    def __init__(self, pipes):
+        self.pipes, self.flags, self.prev = list(pipes), [], None
+
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        self.flags = [p.single_host_thread for p in self.pipes]
+        for p in self.pipes:
+            p.single_host_thread = False
+        if self.prev != 1:
+            torch.set_num_threads(1)
+        return self
+
+    def __exit__(self, *exc):
+        for p, f in zip(self.pipes, self.flags):
+            p.single_host_thread = f
+        if torch.get_num_threads() != self.prev:
+            torch.set_num_threads(self.prev)
+        return False
+
+
 class ChainSet:
     def __init__(self, pipe: ControlAnimationPipeline, cn: Optional[MultiControlNetResidualsPipeline] = None, chains: int = 2):
         if chains < 1:
@@ -62,6 +87,10 @@ class ChainSet:
         """Runs `pipe(**job)` for every job -- chain k takes jobs k, k + chains, ... -- and returns the results in job order.  prime: the
         first job of every chain runs alone (its eager step and the hipGraph capture; pass False once every chain has captured), the rest
         concurrently.  timeout_s: give up (TimeoutError) when the concurrent part takes longer -- the worker threads are daemons."""
+        with one_host_thread(self.pipes):
+            return self._map(jobs, prime, timeout_s)
+
+    def _map(self, jobs, prime, timeout_s):
         n = len(self.pipes)
         results: List[Any] = [None] * len(jobs)
         errors: List[Optional[BaseException]] = [None] * n

@@ -358,15 +358,17 @@ def _run_windows_on_chains(pipe, plan, frames, cfg_of, ip_kw, rank, world, chain
         except BaseException as exc:  # noqa: BLE001 -- re-raised in the caller's thread
             errors[c] = exc
 
-    for c in range(min(chains, len(mine))):
-        run(c, [mine[c]])
-        if errors[c] is not None:
-            raise errors[c]
-    threads = [threading.Thread(target=run, args=(c, mine[c + chains::chains]), name=f"chain{c}", daemon=True) for c in range(chains)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    from .chains import one_host_thread
+    with one_host_thread([fc.pipeline for fc in facades]):
+        for c in range(min(chains, len(mine))):
+            run(c, [mine[c]])
+            if errors[c] is not None:
+                raise errors[c]
+        threads = [threading.Thread(target=run, args=(c, mine[c + chains::chains]), name=f"chain{c}", daemon=True) for c in range(chains)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     for e in errors:
         if e is not None:
             raise e

@@ -45,8 +45,10 @@ def test_two_chains_equal_the_sequential_run_bit_for_bit():
     pipe2, cn2 = fresh()
     chains = ChainSet(pipe2, cn2, chains=2)
     assert chains.pipes[1].unet is pipe2.unet and chains.cns[1].controlnets[0] is nets[0] and chains.pipes[1].scheduler is not pipe2.scheduler
+    threads_before = torch.get_num_threads()
     outs = chains.map(_jobs(f, hw, n_jobs, n_steps, seed=7))
     torch.cuda.synchronize()
+    assert torch.get_num_threads() == threads_before and all(p_.single_host_thread for p_ in chains.pipes)  # (one switch around all chains, restored)
     for p_ in chains.pipes:
         assert p_.graph_fallback_reason is None and p_.graph_replays == n_steps   # both chains replay their own capture
     # each chain kept its own cache slots in the shared models: nobody re-captured after the priming window
