@@ -852,15 +852,14 @@ def measure(args, timer, rank, world, device, headline=True):
             res = cs.map([job(40 + k) for k in range(2 * args.chains)], prime=False, timeout_s=300)  # two windows per chain, all concurrent
             torch.cuda.synchronize()
             tcc = time.perf_counter() - tc1
-            outs = [res]
-            ok = all(torch.isfinite(o.videos).all().item() for oo in outs for o in oo)
+            ok = all(torch.isfinite(o.videos).all().item() for o in res)
             steps_done = 2 * args.chains * steps_per_window
             chains_out = {"chains": args.chains, "windows": 2 * args.chains, "ms_per_step_equivalent": round(1e3 * tcc / steps_done, 3),
                           "frames_per_sec": round(2 * args.chains * f / tcc, 4), "finite": bool(ok),
                           "replays_per_window": [int(p_.graph_replays) for p_ in cs.pipes],
                           "note": "independent windows in flight on one GPU, one pipeline object per chain over shared models; a window's latency "
                                   "is `chains` times the single-chain one; not part of `value`"}
-            del cs, res, outs
+            del cs, res
         except Exception as exc:  # (never lose the headline to the side measurement)
             chains_out = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     vae_ms = None

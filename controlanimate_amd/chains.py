@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import copy
 import threading
+import time
 from typing import Any, Dict, List, Optional, Sequence
 
 import torch
@@ -119,7 +120,6 @@ class ChainSet:
         threads = [threading.Thread(target=run, args=(k, list(range(k + first, len(jobs), n))), name=f"chain{k}", daemon=True) for k in range(n)]
         for t in threads:
             t.start()
-        import time
         deadline = None if timeout_s is None else time.monotonic() + float(timeout_s)
         for t in threads:
             t.join(None if deadline is None else max(0.0, deadline - time.monotonic()))
