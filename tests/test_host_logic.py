@@ -234,3 +234,26 @@ def test_predrawn_sampler_noise_equals_the_references_per_step_draws():
         g = torch.Generator().manual_seed(12)
         big = torch.randn((3,) + shape, generator=g, dtype=torch.float32)
         assert all(torch.equal(big[i], seq[i]) for i in range(3))
+
+
+def test_chain_clones_share_models_and_own_their_loop_state():
+    """controlanimate_amd/chains.py (two windows in flight per GPU): a chain's pipeline is a new loop over the SAME model objects -- its own sampler
+    instance and graph / noise state, the flags of the original; the process-wide intra-op thread switch is taken once around all chains."""
+    import torch
+    from controlanimate_amd.chains import clone_pipeline, clone_residuals_pipeline, one_host_thread
+    from controlanimate_amd.configs import NOISE_SCHEDULER_KWARGS
+    from controlanimate_amd.controlanimation_pipeline import ControlAnimationPipeline
+    from controlanimate_amd.schedulers import get_scheduler
+    unet = object()
+    pipe = ControlAnimationPipeline(vae=None, text_encoder=None, tokenizer=None, unet=None, scheduler=get_scheduler("LCMScheduler", **NOISE_SCHEDULER_KWARGS))
+    pipe.unet = unet
+    pipe.steps_in_flight, pipe.fuse_controlnet_adds, pipe.window_graph = 3, False, True
+    twin = clone_pipeline(pipe)
+    assert twin is not pipe and twin.unet is unet and twin.scheduler is not pipe.scheduler and type(twin.scheduler) is type(pipe.scheduler)
+    assert (twin.steps_in_flight, twin.fuse_controlnet_adds, twin.window_graph, twin.use_hip_graph) == (3, False, True, True)
+    assert twin._graph_state is None and twin._noise_state is None
+    assert clone_residuals_pipeline(None) is None
+    n = torch.get_num_threads()
+    with one_host_thread([pipe, twin]):
+        assert torch.get_num_threads() == 1 and not pipe.single_host_thread and not twin.single_host_thread
+    assert torch.get_num_threads() == n and pipe.single_host_thread and twin.single_host_thread
