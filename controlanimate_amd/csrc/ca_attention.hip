@@ -382,7 +382,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(AttnKParams p) {
 // column -- 37% of the QK^T MFMA work multiplied zeros.  With K16 the chunk behind the DK32 full ones is 16 deep and runs
 // on v_mfma_f32_16x16x16 (a lane holds k = 4g .. 4g+3: 8-byte fragment reads): QK^T costs 48 instead of 64 columns.
 template <int DT, int DK32, int DV16, int QT, int NW, int KB, bool SR, bool FOLD, bool K16 = false>
-__global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
+__global__ __launch_bounds__(NW * 64, (DK32 == 1 && DV16 == 3 && SR && FOLD && K16) ? 4 : 1) void k_attn_dma(AttnKParams p) {  // (d = 40: four waves per SIMD, <= 128 VGPRs)
   // LDS row length (elements): 64 for head dims up to 64; 128 for 65..80 (two 32-deep chunks + the 16-deep one: SD1.5's d = 80 with
   // no padding at all -- round 4: the 1024-token self-attention of the 32x32-latent level ran on the generic kernel at 170 us)
   constexpr int ROW = (DK32 * 32 + (K16 ? 16 : 0)) > 64 ? 128 : 64;
@@ -523,9 +523,13 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   stage(0, 0);
   __syncthreads();  // (vmcnt(0) + barrier)
 
-  auto tile_body = [&](int kv0, int iter, auto tail_c) {
+  auto tile_body = [&](int kv0, int iter, auto tail_c, auto buf_c) {
     constexpr bool TAIL = decltype(tail_c)::value;
-    const int buf = iter & 1;
+    // buf_c: the LDS buffer of this tile as a compile-time constant (the main loop below runs tiles in pairs) -- every fragment address is then
+    // a loop-invariant base plus an immediate offset, instead of ~20 VALU instructions per tile that add the buffer's offset (the kernel is bound
+    // by VALU issue: DESIGN.md section 9); -1 = take it from the iteration count
+    constexpr int BUFC = decltype(buf_c)::value;
+    const int buf = BUFC >= 0 ? BUFC : (iter & 1);
     if (kv0 + KB < p.nk) stage(kv0 + KB, buf ^ 1);
     const u16* Ks = smem + buf * TILE;
     const u16* Vs = Ks + KB * ROW;
@@ -669,8 +673,12 @@ __global__ __launch_bounds__(NW * 64) void k_attn_dma(AttnKParams p) {
   {
     const int nfull = p.nk / KB;
     int iter = 0;
-    for (; iter < nfull; ++iter) tile_body(iter * KB, iter, BoolC<false>{});
-    if (nfull * KB < p.nk) tile_body(nfull * KB, iter, BoolC<true>{});
+    for (; iter + 1 < nfull; iter += 2) {
+      tile_body(iter * KB, iter, BoolC<false>{}, std::integral_constant<int, 0>{});
+      tile_body((iter + 1) * KB, iter + 1, BoolC<false>{}, std::integral_constant<int, 1>{});
+    }
+    for (; iter < nfull; ++iter) tile_body(iter * KB, iter, BoolC<false>{}, std::integral_constant<int, -1>{});
+    if (nfull * KB < p.nk) tile_body(nfull * KB, iter, BoolC<true>{}, std::integral_constant<int, -1>{});
   }
 
 #pragma unroll
